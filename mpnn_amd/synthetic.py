@@ -1,0 +1,153 @@
+"""Deterministic synthetic inputs and weights for the ProteinMPNN hot path.
+
+Everything here is integer-hash based (numpy uint64 arithmetic), so the same
+arrays are regenerated bit-for-bit on any machine: golden fixtures only need to
+store the recipe (seed, shapes) plus the expected outputs.
+
+Input contract produced here is the one `featurize` hands to the model
+(reference: src/mpnn/data/data_utils.py:170-183): X f32 [B,L,4,3] (N, CA, C, O),
+S i64 in [0,20], mask / chain_M f32 in {0,1}, residue_idx i64 with +100 jumps
+between chains and -100 on padding, chain_encoding_all i64 numbered from 1 with
+0 on padding.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def hash_u64(n: int, seed: int) -> np.ndarray:
+    """splitmix64-style hash of (index, seed) -> uint64[n]."""
+    with np.errstate(over="ignore"):
+        x = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        x = x + np.uint64(seed & 0xFFFFFFFF) * np.uint64(0xD1B54A32D192ED03) + np.uint64(0x2545F4914F6CDD1D)
+        x ^= x >> np.uint64(30)
+        x = x * np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x = x * np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return x
+
+
+def hash_uniform(n: int, seed: int) -> np.ndarray:
+    """float32[n] uniform in [-1, 1), exactly reproducible (24-bit mantissa)."""
+    u = (hash_u64(n, seed) >> np.uint64(40)).astype(np.float64)
+    return (u / float(1 << 24) * 2.0 - 1.0).astype(np.float32)
+
+
+def hash_normal(n: int, seed: int) -> np.ndarray:
+    """float32[n] ~ approx N(0,1): sum of 4 hashed uniforms, rescaled (exactly reproducible)."""
+    acc = np.zeros(n, dtype=np.float64)
+    for k in range(4):
+        acc += hash_uniform(n, seed * 4 + k + 1000003).astype(np.float64)
+    return (acc * (3.0 / 4.0) ** 0.5).astype(np.float32)
+
+
+def _name_seed(name: str) -> int:
+    h = 2166136261
+    for ch in name.encode():
+        h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+    return h
+
+
+def fill_parameters_(module: torch.nn.Module, seed: int = 0) -> None:
+    """Overwrite every parameter of `module` with hash-derived values.
+
+    Matrices get a xavier-uniform-sized amplitude (reference init:
+    model_utils.py:423-425), LayerNorm weights 1 +- 0.2, biases +-0.1.
+    Works on any module that exposes named_parameters (reference or ours).
+    """
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            n = p.numel()
+            u = hash_uniform(n, _name_seed(name) ^ (seed * 7919))
+            if p.dim() > 1:
+                fan_out, fan_in = p.shape[0], p.shape[1]
+                amp = (6.0 / (fan_in + fan_out)) ** 0.5
+                if "W_s" in name:  # embedding table
+                    amp = 1.0
+                v = u * np.float32(amp)
+            elif "norm" in name and name.endswith("weight"):
+                v = np.float32(1.0) + np.float32(0.2) * u
+            else:
+                v = np.float32(0.1) * u
+            p.copy_(torch.from_numpy(v.reshape(tuple(p.shape))).to(p.device, p.dtype))
+
+
+def synthetic_backbone(B: int, L: int, seed: int = 0) -> np.ndarray:
+    """Random-walk C-alpha trace (3.8 A steps, mild compaction) with N/C/O placed
+    at ideal bond lengths (1.46 / 1.52 / 1.23 A) in a per-residue random frame.
+    Returns float32 [B, L, 4, 3] in atom order N, CA, C, O.
+    """
+    g = hash_normal(B * L * 3, seed * 11 + 1).reshape(B, L, 3).astype(np.float64)
+    # persistent direction so the chain is locally extended but globally compact
+    step = np.zeros_like(g)
+    cur = g[:, 0] / (np.linalg.norm(g[:, 0], axis=-1, keepdims=True) + 1e-9)
+    pos = np.zeros((B, 3))
+    ca = np.zeros((B, L, 3))
+    for i in range(L):
+        cur = 0.6 * cur + 0.8 * g[:, i] - 0.002 * pos
+        cur = cur / (np.linalg.norm(cur, axis=-1, keepdims=True) + 1e-9)
+        pos = pos + 3.8 * cur
+        ca[:, i] = pos
+        step[:, i] = cur
+    f = hash_normal(B * L * 9, seed * 11 + 2).reshape(B, L, 3, 3).astype(np.float64)
+    u1 = f[:, :, 0] / (np.linalg.norm(f[:, :, 0], axis=-1, keepdims=True) + 1e-9)
+    v = f[:, :, 1] - (f[:, :, 1] * u1).sum(-1, keepdims=True) * u1
+    u2 = v / (np.linalg.norm(v, axis=-1, keepdims=True) + 1e-9)
+    u3 = np.cross(u1, u2)
+    n_at = ca - 1.46 * u1
+    ang = np.deg2rad(111.0)
+    c_dir = -np.cos(ang) * (-u1) + np.sin(ang) * u2  # N-CA-C angle 111 deg
+    c_at = ca + 1.52 * c_dir
+    o_dir = 0.5 * c_dir + 0.6 * u3 + 0.3 * u2
+    o_dir = o_dir / (np.linalg.norm(o_dir, axis=-1, keepdims=True) + 1e-9)
+    o_at = c_at + 1.23 * o_dir
+    X = np.stack([n_at, ca, c_at, o_at], axis=2)
+    return X.astype(np.float32)
+
+
+def synthetic_batch(
+    B: int,
+    L: int,
+    seed: int = 0,
+    lengths: list[int] | None = None,
+    n_chains: int = 1,
+    design_fraction: float = 1.0,
+    device: str | torch.device = "cpu",
+) -> dict[str, torch.Tensor]:
+    """A padded batch obeying the featurize() output contract.
+
+    lengths: valid length per protein (default all L). n_chains: chains per
+    protein (equal split, residue_idx jumps by +100 between chains, cf.
+    data_utils.py:57,120). design_fraction: fraction of chains with chain_M=1.
+    """
+    X = synthetic_backbone(B, L, seed)
+    lengths = list(lengths) if lengths is not None else [L] * B
+    assert len(lengths) == B and max(lengths) <= L
+    S = (hash_u64(B * L, seed * 11 + 3) % np.uint64(21)).astype(np.int64).reshape(B, L)
+    mask = np.zeros((B, L), np.float32)
+    chain_M = np.zeros((B, L), np.float32)
+    residue_idx = np.full((B, L), -100, np.int64)
+    chain_enc = np.zeros((B, L), np.int64)
+    n_design = max(1, int(round(design_fraction * n_chains)))
+    for b, n in enumerate(lengths):
+        mask[b, :n] = 1.0
+        bounds = [round(c * n / n_chains) for c in range(n_chains + 1)]
+        for c in range(n_chains):
+            lo, hi = bounds[c], bounds[c + 1]
+            residue_idx[b, lo:hi] = np.arange(lo, hi) + 100 * c
+            chain_enc[b, lo:hi] = c + 1
+            if c < n_design:
+                chain_M[b, lo:hi] = 1.0
+        X[b, n:] = 0.0
+        S[b, n:] = 0
+    # decoding order: a fixed permutation per protein
+    key = hash_uniform(B * L, seed * 11 + 4).reshape(B, L)
+    order = np.argsort(key, axis=-1, kind="stable").astype(np.int64)
+    out = dict(X=X, S=S, mask=mask, chain_M=chain_M, residue_idx=residue_idx,
+               chain_encoding_all=chain_enc, fix_order=order)
+    return {k: torch.from_numpy(v).to(device) for k, v in out.items()}

@@ -1,0 +1,84 @@
+import ast
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN)
+                  if f.endswith(".npz") and f[0] in "abcdef" or f.startswith("g_all"))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    rec = {k: z[k] for k in z.files}
+    kw = {}
+    if "model_kwargs" in rec:
+        kw = ast.literal_eval(str(rec.pop("model_kwargs")))
+        kw = {k: (None if v == "none" else v) for k, v in kw.items()}
+    return rec, kw
+
+
+class _Holder(torch.nn.Module):
+    """A bare parameter container with reference-shaped state_dict keys."""
+
+    def __init__(self, shapes):
+        super().__init__()
+        self._keys = list(shapes)
+        for i, (k, shp) in enumerate(shapes.items()):
+            self.register_parameter(f"p{i}", torch.nn.Parameter(torch.zeros(shp)))
+
+    def named_parameters(self, *a, **k):  # report reference key names
+        for i, key in enumerate(self._keys):
+            yield key, getattr(self, f"p{i}")
+
+
+def hashed_state_dict(model_kwargs, seed=0):
+    """Reference-shaped state_dict filled by mpnn_amd.synthetic.fill_parameters_ (no reference import)."""
+    from mpnn_amd.params import param_shapes
+    from mpnn_amd.synthetic import fill_parameters_
+
+    shapes = param_shapes(use_virtual_center=bool(model_kwargs.get("use_virtual_center", False)),
+                          occupancy_cutoff=model_kwargs.get("occupancy_cutoff"))
+    h = _Holder(shapes)
+    fill_parameters_(h, seed=seed)
+    return {k: p.detach() for k, p in h.named_parameters()}
+
+
+def oracle_cfg(model_kwargs):
+    from oracle.mpnn_oracle import Config
+
+    return Config(k_neighbors=model_kwargs.get("k_neighbors", 32),
+                  edge_cutoff=model_kwargs.get("edge_cutoff"),
+                  use_virtual_center=bool(model_kwargs.get("use_virtual_center", False)),
+                  occupancy_cutoff=model_kwargs.get("occupancy_cutoff"))
+
+
+def untied_edge_mask(D_neighbors, D_full=None):
+    """True where a neighbour slot's rank is well defined: its distance differs from both adjacent
+    slots' and (when the full [B,L,L] adjusted-distance matrix is given) from every other column's,
+    which also catches a last slot that ties with the first excluded candidate."""
+    D = np.asarray(D_neighbors)
+    ne_prev = np.ones_like(D, bool)
+    ne_next = np.ones_like(D, bool)
+    ne_prev[..., 1:] = D[..., 1:] != D[..., :-1]
+    ne_next[..., :-1] = D[..., :-1] != D[..., 1:]
+    ok = ne_prev & ne_next
+    if D_full is not None:
+        F = np.asarray(D_full)
+        mult = (F[..., None, :] == D[..., :, None]).sum(-1)  # [B,L,K] multiplicity of each kept value
+        ok &= mult == 1
+    return ok

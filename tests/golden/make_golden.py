@@ -1,0 +1,172 @@
+"""Generate golden fixtures from the REAL reference (build container only).
+
+Imports /root/reference/src/mpnn/models/model_utils.py by file path (it needs
+only itertools/numpy/torch), fills its parameters with the hash-based closed
+form in mpnn_amd.synthetic.fill_parameters_, runs it in eval mode on synthetic
+batches and stores inputs + outputs as small .npz files next to this script.
+The reference file itself never travels: only these vectors are committed.
+
+Run:  python tests/golden/make_golden.py
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from mpnn_amd.synthetic import fill_parameters_, hash_normal, synthetic_batch  # noqa: E402
+
+REF = "/root/reference/src/mpnn/models/model_utils.py"
+
+# name -> (model kwargs, batch kwargs, extras)
+CASES = {
+    # (a) all valid
+    "a_valid_B2_L64": (dict(k_neighbors=48), dict(B=2, L=64, seed=1), {}),
+    "a_short_B1_L30": (dict(k_neighbors=48), dict(B=1, L=30, seed=2), {}),
+    # (b) padded, every valid length >= K, 2 chains, mixed chain_M
+    "b_padded_B3_L96": (dict(k_neighbors=48),
+                        dict(B=3, L=96, seed=3, lengths=[96, 70, 50], n_chains=2, design_fraction=0.5), {}),
+    # (c) valid length < K: ties among masked columns
+    "c_ties_B2_L64": (dict(k_neighbors=48), dict(B=2, L=64, seed=4, lengths=[64, 20]), {}),
+    # (d) virtual centre
+    "d_vcenter_B2_L64": (dict(k_neighbors=48, use_virtual_center=True), dict(B=2, L=64, seed=5), {}),
+    # (e) edge cutoff + occupancy
+    "e_cutoff_occ_B2_L80": (dict(k_neighbors=32, edge_cutoff=15.0, occupancy_cutoff=6.0),
+                            dict(B=2, L=80, seed=6, lengths=[80, 61]), {}),
+    # (f) internal random order under a fixed CPU seed, plus backbone noise, K=30
+    "f_randorder_B2_L64": (dict(k_neighbors=30), dict(B=2, L=64, seed=7, n_chains=2, design_fraction=0.5),
+                           dict(random_order=True, backbone_noise=True)),
+    # (g) everything on, K=48, longer
+    "g_all_B2_L128": (dict(k_neighbors=48, use_virtual_center=True, edge_cutoff=18.0, occupancy_cutoff=8.0),
+                      dict(B=2, L=128, seed=8, lengths=[128, 100], n_chains=3, design_fraction=0.67), {}),
+}
+
+
+def load_reference():
+    spec = importlib.util.spec_from_file_location("ref_model_utils", REF)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def run_case(ref, name, mkw, bkw, extra):
+    torch.manual_seed(0)
+    model = ref.ProteinMPNN(augment_eps=0.0, dropout=0.0, **mkw).eval()
+    fill_parameters_(model, seed=0)
+    batch = synthetic_batch(**bkw)
+    X, S, mask, chain_M = batch["X"], batch["S"], batch["mask"], batch["chain_M"]
+    ridx, cenc, order = batch["residue_idx"], batch["chain_encoding_all"], batch["fix_order"]
+    noise = None
+    if extra.get("backbone_noise"):
+        noise = torch.from_numpy(0.05 * hash_normal(X.numel(), 99).reshape(tuple(X.shape)))
+
+    rec = {}
+    # --- hooks to capture intermediates
+    caps = {}
+    hooks = []
+    hooks.append(model.features.register_forward_hook(lambda m, i, o: caps.__setitem__("features", o)))
+    hooks.append(model.W_e.register_forward_hook(lambda m, i, o: caps.__setitem__("h_E0", o)))
+    for l, layer in enumerate(model.encoder_layers):
+        hooks.append(layer.register_forward_hook(lambda m, i, o, l=l: caps.__setitem__(f"enc{l}", o)))
+    for l, layer in enumerate(model.decoder_layers):
+        hooks.append(layer.register_forward_hook(lambda m, i, o, l=l: caps.__setitem__(f"dec{l}", o)))
+    # the D_neighbors tensor is not returned by features(): capture from _dist
+    orig_dist = model.features._dist
+    def dist_spy(Xc, m, eps=1e-6):
+        out = orig_dist(Xc, m, eps)
+        caps["dist"] = out
+        return out
+    model.features._dist = dist_spy
+
+    with torch.no_grad():
+        if extra.get("random_order"):
+            torch.manual_seed(1234)
+            order_noise = torch.randn(chain_M.shape)  # same draw forward() will make
+            torch.manual_seed(1234)
+            lp = model(X, S, mask, chain_M, ridx, cenc, fix_order=None, fix_backbone_noise=noise)
+            rec["order_noise"] = order_noise.numpy()
+        else:
+            lp = model(X, S, mask, chain_M, ridx, cenc, fix_order=order, fix_backbone_noise=noise)
+    for h in hooks:
+        h.remove()
+
+    E, E_idx, occ, edge_mask = caps["features"]
+    rec.update(X=X.numpy(), S=S.numpy(), mask=mask.numpy(), chain_M=chain_M.numpy(),
+               residue_idx=ridx.numpy(), chain_encoding_all=cenc.numpy(), fix_order=order.numpy())
+    if noise is not None:
+        rec["backbone_noise"] = noise.numpy()
+    rec["E_idx"] = E_idx.numpy()
+    rec["D_neighbors"] = caps["dist"][0].numpy()
+    rec["E_head"] = E[:, :6].numpy().astype(np.float32)  # first 6 residues in full
+    rec["E_sum"] = E.double().sum(-1).numpy()            # [B,L,K] checksums for the rest
+    rec["E_sqsum"] = (E.double() ** 2).sum(-1).numpy()
+    if occ is not None:
+        rec["occupancy"] = occ.numpy()
+    if edge_mask is not None:
+        rec["edge_mask"] = edge_mask.numpy()
+    rec["h_E0_sum"] = caps["h_E0"].double().sum(-1).numpy()  # [B,L,K] checksum of W_e(E)
+    for l in range(len(model.encoder_layers)):
+        hv, he = caps[f"enc{l}"]
+        rec[f"enc{l}_h_V"] = hv.numpy()
+        rec[f"enc{l}_h_E_sum"] = he.double().sum(-1).numpy()
+        if l == len(model.encoder_layers) - 1:
+            rec[f"enc{l}_h_E_head"] = he[:, :6].numpy()
+    for l in range(len(model.decoder_layers)):
+        rec[f"dec{l}_h_V"] = caps[f"dec{l}"].numpy()
+    rec["log_probs"] = lp.numpy()
+    kw = {k: (v if v is not None else "none") for k, v in mkw.items()}
+    rec["model_kwargs"] = np.array(repr(kw))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    print(f"{name}: log_probs {tuple(lp.shape)} sum {lp.double().sum():.6f}")
+
+
+def training_case(ref):
+    """Loss + parameter-gradient summary at B=2, L=64 (train.py:63-73 loss, eval-mode dropout=0)."""
+    torch.manual_seed(0)
+    model = ref.ProteinMPNN(augment_eps=0.0, dropout=0.0, k_neighbors=48).train()
+    fill_parameters_(model, seed=0)
+    b = synthetic_batch(B=2, L=64, seed=9, lengths=[64, 52], n_chains=2, design_fraction=0.5)
+    lp = model(b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"],
+               fix_order=b["fix_order"])
+    S1 = torch.nn.functional.one_hot(b["S"], 21).float()
+    S1 = S1 + 0.1 / 21
+    S1 = S1 / S1.sum(-1, keepdim=True)
+    loss = (-(S1 * lp).sum(-1) * (b["mask"] * b["chain_M"])).sum() / 2000.0
+    loss.backward()
+    rec = {k: v.numpy() for k, v in b.items()}
+    rec["loss"] = np.array(loss.item())
+    rec["log_probs"] = lp.detach().numpy()
+    for n, p in model.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        rec["gnorm/" + n] = np.array(g.double().norm().item())
+        rec["ghead/" + n] = g.reshape(-1)[:16].numpy()
+    np.savez_compressed(os.path.join(HERE, "h_train_B2_L64.npz"), **rec)
+    print("h_train: loss", loss.item())
+
+
+def c2_checksum(ref):
+    """C2-shaped record (B=32 would take ~20 s and 10 GB on CPU; B=4 of the same L/K, checksum only)."""
+    torch.manual_seed(0)
+    model = ref.ProteinMPNN(augment_eps=0.0, dropout=0.0, k_neighbors=48).eval()
+    fill_parameters_(model, seed=0)
+    b = synthetic_batch(B=4, L=512, seed=10)
+    with torch.no_grad():
+        lp = model(b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"],
+                   fix_order=b["fix_order"])
+    rec = dict(B=np.array(4), L=np.array(512), seed=np.array(10),
+               lp_sum=np.array(lp.double().sum().item()), lp_abs_sum=np.array(lp.double().abs().sum().item()),
+               lp_rowsum=lp.double().sum(-1).numpy(), lp_head=lp[:, :8].numpy(),
+               lp_argmax=lp.argmax(-1).numpy().astype(np.int8))
+    np.savez_compressed(os.path.join(HERE, "g_c2shape_B4_L512.npz"), **rec)
+    print("c2 checksum: sum", rec["lp_sum"])
+
+
+if __name__ == "__main__":
+    ref = load_reference()
+    for name, (mkw, bkw, extra) in CASES.items():
+        run_case(ref, name, mkw, bkw, extra)
+    training_case(ref)
+    c2_checksum(ref)

@@ -1,0 +1,123 @@
+"""Pin the CPU oracle against golden vectors produced by the real reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, hashed_state_dict, load_golden, oracle_cfg, untied_edge_mask
+from oracle import mpnn_oracle as orc
+
+T = torch.from_numpy
+
+
+def _run(rec, kw, formulation, adopt_ties=False):
+    sd = hashed_state_dict(kw)
+    cfg = oracle_cfg(kw)
+    noise = T(rec["backbone_noise"]) if "backbone_noise" in rec else None
+    if "order_noise" in rec:
+        fix_order, order_noise = None, T(rec["order_noise"])
+    else:
+        fix_order, order_noise = T(rec["fix_order"]), None
+    with torch.no_grad():
+        return orc.forward(sd, cfg, T(rec["X"]), T(rec["S"]), T(rec["mask"]), T(rec["chain_M"]),
+                           T(rec["residue_idx"]), T(rec["chain_encoding_all"]), fix_order=fix_order,
+                           fix_backbone_noise=noise, order_noise=order_noise,
+                           formulation=formulation, keep=True,
+                           E_idx_given=T(rec["E_idx"]) if adopt_ties else None)
+
+
+@pytest.mark.parametrize("formulation", ["reference", "edge"])
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_matches_reference(name, formulation):
+    rec, kw = load_golden(name)
+    out = _run(rec, kw, formulation)
+    mask = rec["mask"].astype(bool)
+    cfg = oracle_cfg(kw)
+    Xn = T(rec["X"]) + (T(rec["backbone_noise"]) if "backbone_noise" in rec else 0)
+    D_full = orc.adjusted_distances(Xn[:, :, 1], T(rec["mask"]), cfg).numpy()
+    untied = untied_edge_mask(rec["D_neighbors"], D_full)
+    # neighbour indices: bit-exact wherever the rank is well defined
+    E_idx = out["E_idx"].numpy()
+    assert np.array_equal(E_idx[untied], rec["E_idx"][untied])
+    np.testing.assert_array_equal(out["D_neighbors"].numpy(), rec["D_neighbors"])
+    if "edge_mask" in rec:
+        np.testing.assert_array_equal(out["edge_mask"].numpy(), rec["edge_mask"])
+    if "occupancy" in rec:
+        np.testing.assert_allclose(out["occupancy"].numpy(), rec["occupancy"], rtol=1e-6, atol=1e-7)
+    # rows whose whole neighbour list is untied are comparable element-wise
+    row_ok = untied.all(-1) & mask
+    assert row_ok[mask].mean() > 0.1 or "c_ties" in name
+    E_head = out["E"][:, :6].numpy()
+    sel = row_ok[:, :6]
+    np.testing.assert_allclose(E_head[sel], rec["E_head"][sel], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(out["E"].double().sum(-1).numpy()[row_ok], rec["E_sum"][row_ok], atol=5e-5)
+    for l in range(3):
+        np.testing.assert_allclose(out["h_V_enc"][l].numpy()[row_ok], rec[f"enc{l}_h_V"][row_ok],
+                                   rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(out["h_V_dec"][l].numpy()[row_ok], rec[f"dec{l}_h_V"][row_ok],
+                                   rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_log_probs(name):
+    """log_probs within 1e-4 relative (abs floor 1e-1) on every valid row.  Where a protein has fewer
+    valid residues than K, WHICH padded columns fill the tied slots is torch.topk-implementation
+    defined and does change the decoder output (their decoding rank differs), so for that fixture the
+    reference's own E_idx is adopted and everything downstream of the neighbour search is compared."""
+    rec, kw = load_golden(name)
+    out = _run(rec, kw, "edge", adopt_ties=True)
+    mask = rec["mask"].astype(bool)
+    lp, ref = out["log_probs"].numpy()[mask], rec["log_probs"][mask]
+    err = np.abs(lp - ref) / np.maximum(np.abs(ref), 1e-1)
+    assert err.max() < 1e-4, err.max()
+    # padded rows: log_softmax(W_out.bias) exactly (h_V is zeroed by mask_V)
+    np.testing.assert_allclose(out["log_probs"].numpy()[~mask], rec["log_probs"][~mask], rtol=1e-6, atol=1e-6)
+
+
+def test_order_mask_formulations_agree():
+    g = torch.Generator().manual_seed(0)
+    B, L, K = 3, 40, 12
+    order = torch.stack([torch.randperm(L, generator=g) for _ in range(B)])
+    E_idx = torch.randint(0, L, (B, L, K), generator=g)
+    a = orc.order_mask_backward(order, E_idx, "reference")
+    b = orc.order_mask_backward(order, E_idx, "edge")
+    assert torch.equal(a, b)
+
+
+def test_virtual_center_known_answer():
+    """Geometry KAT from the reference's tests/test_virtual_center.py:49-118: one residue with
+    N=(0,0,0), CA=(1.46,0,0), C at 111 deg: |V-CA| = 3.06, angle(V,CA,CB) = 90 deg,
+    dihedral(V,CA,CB,N) = 0."""
+    n = torch.tensor([[[0.0, 0.0, 0.0]]])
+    ca = torch.tensor([[[1.46, 0.0, 0.0]]])
+    ang = np.deg2rad(111.0)
+    c = ca + 1.52 * torch.tensor([[[-np.cos(ang), np.sin(ang), 0.0]]], dtype=torch.float32)
+    X = torch.stack([n, ca, c, c + 1.0], dim=2)
+    atoms = orc.backbone_atoms(X, orc.Config(use_virtual_center=True))
+    cb, v = atoms[4][0, 0], atoms[5][0, 0]
+    ca0, n0 = ca[0, 0], n[0, 0]
+    assert abs(torch.norm(v - ca0).item() - 3.06) < 1e-4
+    cosang = torch.dot(v - ca0, cb - ca0) / (torch.norm(v - ca0) * torch.norm(cb - ca0))
+    assert abs(cosang.item()) < 1e-4
+    # dihedral V-CA-CB-N
+    b0, b1, b2 = ca0 - v, cb - ca0, n0 - cb
+    n1, n2 = torch.linalg.cross(b0, b1), torch.linalg.cross(b1, b2)
+    m1 = torch.linalg.cross(n1, b1 / torch.norm(b1))
+    dih = torch.atan2(torch.dot(m1, n2), torch.dot(n1, n2))
+    assert abs(dih.item()) < 1e-3 or abs(abs(dih.item()) - np.pi) < 1e-3
+
+
+def test_c2_shape_checksum():
+    """L=512, K=48 record generated from the reference at B=4 (checksums only)."""
+    z = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "g_c2shape_B4_L512.npz"))
+    from mpnn_amd.synthetic import synthetic_batch
+    b = synthetic_batch(B=1, L=512, seed=10)  # proteins are independent: check the first one
+    b4 = synthetic_batch(B=4, L=512, seed=10)
+    sd = hashed_state_dict({})
+    cfg = oracle_cfg(dict(k_neighbors=48))
+    with torch.no_grad():
+        lp = orc.forward(sd, cfg, b4["X"][:1], b4["S"][:1], b4["mask"][:1], b4["chain_M"][:1],
+                         b4["residue_idx"][:1], b4["chain_encoding_all"][:1],
+                         fix_order=b4["fix_order"][:1], formulation="edge")
+    np.testing.assert_allclose(lp.double().sum(-1).numpy(), z["lp_rowsum"][:1], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(lp[:, :8].numpy(), z["lp_head"][:1], rtol=1e-4, atol=1e-4)
