@@ -1,0 +1,27 @@
+# Builds the C-ABI HIP library for gfx950 (cross-compiles without a GPU) and the oracle helpers.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := mpnn_amd/csrc
+OUT   := mpnn_amd/libmpnn_hip.so
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wno-unused-result
+OBJS  := $(CSRC)/mpnn_featurizer.o $(CSRC)/mpnn_layers.o $(CSRC)/mpnn_abi.o
+
+all: $(OUT)
+
+# neighbour search must round like the reference's separate ATen ops: no FMA contraction there
+$(CSRC)/mpnn_featurizer.o: $(CSRC)/mpnn_featurizer.hip $(CSRC)/mpnn_common.h
+	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $< -o $@
+
+$(CSRC)/mpnn_layers.o: $(CSRC)/mpnn_layers.hip $(CSRC)/mpnn_common.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(CSRC)/mpnn_abi.o: $(CSRC)/mpnn_abi.cpp
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OUT): $(OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
+
+clean:
+	rm -f $(OBJS) $(OUT)
+
+.PHONY: all clean

@@ -1,0 +1,120 @@
+/* C ABI of libmpnn_hip.so: gfx950 (MI355X) kernels for the ProteinMPNN message-passing hot path.
+ *
+ * The reference (FridrichMethod/MPNN) has no native plugin ABI: its hot path is the Python
+ * nn.Module `ProteinMPNN.forward` in src/mpnn/models/model_utils.py, dispatching to ATen ops.
+ * Each entry point below replaces the ATen op sequence of the cited reference lines; the
+ * Python module `mpnn_amd` (same constructor / forward / state_dict as the reference) binds
+ * them with ctypes.  All citations are to src/mpnn/models/model_utils.py.
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is DEVICE memory owned by the caller (hipMalloc or a
+ *     torch tensor).  The library never allocates, frees or retains pointers and never synchronises.
+ *   - `stream` is a hipStream_t passed as void*; kernels are launched on it only.
+ *   - return 0 on success; -1 for rejected arguments; otherwise the hipError_t of the launch.
+ *     mpnn_last_error() returns a thread-local message.  No C++ exception crosses the ABI.
+ *   - fp32 everywhere; hidden size is fixed at 128 (the reference's only used value), K <= 64.
+ *   - "packed" weights are in the MFMA A-fragment layout produced by mpnn_pack_linear.
+ *   - "hE_frag" is the edge tensor in fragment layout [node][8][KT][64][4] floats, KT = ceil(K/16):
+ *       hE_frag[n][t][c][lane][r] = h_E[n, 16c + (lane&15), 16t + 4(lane>>4) + r]
+ *     (size n_nodes * 8 * KT * 256 floats).  Convert with mpnn_edges_to/from_natural.
+ *   - E_idx32 is the neighbour list as int32 [node][16*KT], slots >= K filled with the node itself.
+ */
+#ifndef MPNN_HIP_H
+#define MPNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int mpnn_version(void);
+const char* mpnn_last_error(void);
+
+/* nn.Linear weight W[out_f, ld] columns [col0, col0+in_f) -> packed[ceil(out/16)][ceil(in/16)][64][4],
+ * zero padded.  Weight layout prep for every Linear on the path (:64-69, :112-114, :147-148, :212, :400, :412). */
+int mpnn_pack_linear(const float* W, int out_f, int in_f, int ld, int col0, float* packed, void* stream);
+
+/* PositionalEncodings as a table: table[d][p] = W[p][d] + bias[p]  (one_hot(d) @ W^T + b, :168-177). */
+int mpnn_pos_table(const float* W, const float* bias, int nbuckets /*66*/, int npos /*16*/, float* table,
+                   void* stream);
+
+/* X[B,L,4,3] (+ optional noise, :311-315) -> atoms[B*L][6][4] = N,CA,C,O, virtual CB (:317-320),
+ * virtual centre V (:215-230); ca_soa[B][4][L] = CA.x, CA.y, CA.z, mask. */
+int mpnn_backbone_atoms(const float* X, const float* noise, const float* mask, int B, int L, float* atoms,
+                        float* ca_soa, void* stream);
+
+/* ProteinFeatures._dist (:270-289): K nearest by the masked / cutoff-adjusted CA distance, ascending, ties by
+ * column index.  edge_cutoff <= 0 means none.  E_idx64 [B,L,K], D_neighbors [B,L,K], edge_mask [B,L,K] may be
+ * NULL; E_idx32 [B*L][16*ceil(K/16)] is required. */
+int mpnn_knn_topk(const float* ca_soa, int B, int L, int K, float edge_cutoff, int64_t* E_idx64, int32_t* E_idx32,
+                  float* D_neighbors, float* edge_mask, void* stream);
+
+/* ProteinFeatures._compute_occupancy (:232-268) on the virtual centres in `atoms`; occ[B*L]. */
+int mpnn_occupancy(const float* atoms, const float* mask, int B, int L, float cutoff, float* occ, void* stream);
+
+/* RBF (:291-307, :344-347) + positional (:349-356) features -> edge_embedding + norm_edges (:357-359) -> W_e (:464).
+ * n_atoms 5 or 6 (virtual centre).  Wemb_packed from edge_embedding.weight [128, 16+16*n_atoms^2];
+ * rbf_mu = the 16 Gaussian centres.  E_natural [B,L,K,128] (the reference's `E`) may be NULL. */
+int mpnn_edge_features(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
+                       const int64_t* chain_labels, const float* pos_table, const float* rbf_mu,
+                       const float* Wemb_packed, const float* ln_w, const float* ln_b, const float* We_packed,
+                       const float* We_bias, int B, int L, int K, int n_atoms, float* E_natural, float* hE_frag,
+                       void* stream);
+
+/* layout converters for API surfaces that expose h_E as [n_nodes, K, 128] (EncLayer / features, :73, :360). */
+int mpnn_edges_to_natural(const float* hE_frag, int n_nodes, int K, float* natural, void* stream);
+int mpnn_edges_from_natural(const float* natural, int n_nodes, int K, float* hE_frag, void* stream);
+
+/* decoding_order -> rank (inverse permutation): replaces the one_hot + O(L^3) einsum (:492-506). */
+int mpnn_order_rank(const int64_t* order, int B, int L, int32_t* rank, void* stream);
+/* mask_bw / mask_fw [B,L,K] (:507-519); edge_mask may be NULL. */
+int mpnn_order_masks(const int32_t* rank, const int64_t* E_idx64, const float* mask, const float* edge_mask, int B,
+                     int L, int K, float* mask_bw, float* mask_fw, void* stream);
+
+/* EncLayer message (:75-81) with W1 split per input block and W3 hoisted:
+ *   gsum[i] = sum_k m_ik gelu(W2 gelu(P_i + Q_{j(i,k)} + W1b e_ik) + b2),  cnt[i] = sum_k m_ik,
+ *   m_ik = mask_i mask_j edge_mask_ik (:467-470).  P = W1a h + b1 and Q = W1c h are columns
+ *   [offP, offP+128) / [offQ, offQ+128) of the node-projection buffer PQ (row stride ldpq). */
+int mpnn_enc_message(const float* hE_frag, const float* PQ, int ldpq, int offP, int offQ, const int32_t* E_idx32,
+                     const float* mask, const float* edge_mask, const float* W1b_packed, const float* W2_packed,
+                     const float* b2, int B, int L, int K, float* gsum, float* cnt, void* stream);
+
+/* EncLayer edge update (:90-95), in place on hE_frag:
+ *   e_ik <- LN3(e_ik + W13 gelu(W12 gelu(P'_i + Q'_j + W11b e_ik) + b12) + b13). */
+int mpnn_enc_edge_update(float* hE_frag, const float* PQ, int ldpq, int offP, int offQ, const int32_t* E_idx32,
+                         const float* W11b_packed, const float* W12_packed, const float* b12,
+                         const float* W13_packed, const float* b13, const float* ln_w, const float* ln_b, int B,
+                         int L, int K, void* stream);
+
+/* Decoder input assembly + DecLayer message (:478-483, :507-525, :121-127), nothing materialised:
+ *   acc0 = Pa_i + bw_ik (TS[S_j] + PV_j) + fw_ik PVenc_j,   gsum[i] = sum_{k<K} gelu(W2 gelu(acc0 + W1b (bw+fw) e_ik) + b2)
+ *   Pa = W1a h + b1, PV = W1d h (columns of PQ); PVenc = W1d h_enc; TS = W1c W_s^T (per-letter table, row stride ldts). */
+int mpnn_dec_message(const float* hE_frag, const float* PQ, int ldpq, int offPa, int offPV, const float* PVenc,
+                     int ldenc, int offEnc, const float* TS, int ldts, int offTS, const int64_t* S,
+                     const int32_t* rank, const int32_t* E_idx32, const float* mask, const float* edge_mask,
+                     const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K, float* gsum,
+                     void* stream);
+
+/* Node update shared by EncLayer / DecLayer (:81-88, :127-137, FFN :151-155) followed by the next kernels'
+ * node projections:  dh = (W3 gsum + cnt b3) / scale;  x = LN1(h + dh);  h' = mask LN2(x + FFN(x));
+ *   PQ[n, 128 p : 128 (p+1)] = Wproj_p h' + bproj_p,  p < nproj.
+ * cnt == NULL uses cnt_const for every node (decoder: K).  do_update = 0 only projects hV_in. */
+int mpnn_node_update(const float* hV_in, const float* gsum, const float* cnt, float cnt_const, const float* mask,
+                     const float* W3_packed, const float* b3, const float* ln1_w, const float* ln1_b,
+                     const float* Win_packed, const float* b_in, const float* Wout_packed, const float* b_out,
+                     const float* ln2_w, const float* ln2_b, float scale, int do_update, const float* Wproj_packed,
+                     const float* bproj, int nproj, int n_nodes, float* hV_out, float* PQ, void* stream);
+
+/* occupancy_mlp (:414-421, :461-462): hV = LN(W2 gelu(w0 occ + b0) + b2). */
+int mpnn_occupancy_mlp(const float* occ, const float* w0, const float* b0, const float* W2_packed, const float* b2,
+                       const float* ln_w, const float* ln_b, int n_nodes, float* hV, void* stream);
+
+/* W_out + log_softmax (:527-528); n_letters <= 32; log_probs [n_nodes, n_letters]. */
+int mpnn_logits_log_softmax(const float* hV, const float* Wout_packed, const float* bias, int n_letters, int n_nodes,
+                            float* log_probs, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPNN_HIP_H */

@@ -1,0 +1,86 @@
+"""ctypes binding of libmpnn_hip.so (C ABI in include/mpnn_hip.h).
+
+The library is built in-tree by `make` / `__graft_entry__.build()`.  There is no
+CPU fallback: if the shared object is missing, or a call fails, a RuntimeError
+is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: the library binds to the HIP runtime torch loaded)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpnn_hip.so")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+# name -> argtypes (all return int except where noted)
+SIGNATURES = {
+    "mpnn_pack_linear": [_P, _I, _I, _I, _I, _P, _P],
+    "mpnn_pos_table": [_P, _P, _I, _I, _P, _P],
+    "mpnn_backbone_atoms": [_P, _P, _P, _I, _I, _P, _P, _P],
+    "mpnn_knn_topk": [_P, _I, _I, _I, _F, _P, _P, _P, _P, _P],
+    "mpnn_occupancy": [_P, _P, _I, _I, _F, _P, _P],
+    "mpnn_edge_features": [_P] * 11 + [_I, _I, _I, _I, _P, _P, _P],
+    "mpnn_edges_to_natural": [_P, _I, _I, _P, _P],
+    "mpnn_edges_from_natural": [_P, _I, _I, _P, _P],
+    "mpnn_order_rank": [_P, _I, _I, _P, _P],
+    "mpnn_order_masks": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "mpnn_enc_message": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "mpnn_enc_edge_update": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "mpnn_dec_message": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I,
+                         _P, _P],
+    "mpnn_node_update": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _I, _I, _P,
+                         _P, _P],
+    "mpnn_occupancy_mlp": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
+    "mpnn_logits_log_softmax": [_P, _P, _P, _I, _I, _P, _P],
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and return the library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP extension first (`make` at the repo root or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`). mpnn_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _I
+    lib.mpnn_version.restype = _I
+    lib.mpnn_version.argtypes = []
+    lib.mpnn_last_error.restype = ctypes.c_char_p
+    lib.mpnn_last_error.argtypes = []
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be contiguous."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "mpnn_amd kernels need contiguous tensors"
+    return t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.mpnn_last_error().decode(errors="replace")
+        raise RuntimeError(f"{name} failed (code {rc}): {msg}")

@@ -1,0 +1,165 @@
+// Shared device helpers for the gfx950 ProteinMPNN kernels.
+//
+// Tile algebra used by every edge-/node-level kernel (one wavefront = one tile):
+//   * v_mfma_f32_16x16x4_f32 computes D[16x16] += A[16x4] * B[4x16] with
+//       A: lane l holds A[row = l&15][k = l>>4]
+//       B: lane l holds B[k = l>>4][col = l&15]
+//       D: lane l holds D[row = 4*(l>>4) + r][col = l&15], r = 0..3
+//   * we always compute  Y^T = W * X^T : rows = output features, cols = items
+//     (edges of one residue, or nodes).  An item lives on lane&15 ("column"),
+//     and its 128 features are spread over quarter g = lane>>4, tile t = 0..7
+//     and register r = 0..3 as  feature = 16*t + 4*g + r.
+//   * consequently the D registers of one layer ARE the B operands of the next
+//     layer (k-step (t, r) covers features {16t + 4g + r : g = 0..3}); no LDS
+//     round trip or shuffle between the layers of an MLP.
+//   * weights are pre-packed ("A-fragment layout") as float4 Wp[t_out][t_in][lane]
+//     with Wp[to][ti][l][r] = W[16*to + (l&15)][16*ti + 4*(l>>4) + r], so one
+//     16-byte read per lane feeds 4 k-steps.
+//   * edge tensors are stored in HBM in the same fragment layout
+//       hE[node][t(8)][c(KT)][lane(64)][r(4)]
+//     = h_E[node, edge 16c + (lane&15), feature 16t + 4(lane>>4) + r]
+//     so a wave streams a residue's edges with perfectly coalesced 1 KiB reads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MPNN_H 128          // hidden size the kernels are specialised for
+#define MPNN_NT 8           // 16-row tiles per 128 features
+#define MPNN_LN_EPS 1e-5f
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// erf with |abs err| < 2.5e-7 (Abramowitz-Stegun 7.1.26 evaluated in fp32)
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __expf(-ax * ax);
+  const float y = fmaf(-p, e, 1.0f);
+  return copysignf(y, x);
+}
+
+// exact-erf GELU (nn.GELU() default; reference model_utils.py:70,115,149)
+__device__ __forceinline__ float gelu(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ f32x4 gelu4(f32x4 v) {
+  f32x4 o;
+  o.x = gelu(v.x); o.y = gelu(v.y); o.z = gelu(v.z); o.w = gelu(v.w);
+  return o;
+}
+
+// in-place GELU over a register tile; the scheduling fence per row keeps live ranges short
+template <int NT_, int KT>
+__device__ __forceinline__ void tile_gelu(f32x4 (&V)[NT_][KT]) {
+#pragma unroll
+  for (int t = 0; t < NT_; ++t) {
+#pragma unroll
+    for (int c = 0; c < KT; ++c) V[t][c] = gelu4(V[t][c]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// sum over the 4 quarter-lanes that hold the same column (lane&15)
+__device__ __forceinline__ float quarter_sum(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// sum over the 16 columns of a quarter (lanes with the same lane>>4)
+__device__ __forceinline__ float column_sum(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+
+// Y[to][c] += Wp[to][ti] * X[ti][c]   for to in [TO0, TO1), ti in [0, NTI)
+//   Wp: packed weights (LDS or global), float4 per lane, layout [to][NTI][64]
+//   X : B operands, X[ti][c] is an f32x4 (r = 0..3)
+template <int KT, int NTI, int TO0, int TO1, typename WPtr>
+__device__ __forceinline__ void tile_gemm(WPtr Wp, int lane, const f32x4 (&X)[NTI][KT],
+                                          f32x4 (&Y)[TO1 - TO0][KT]) {
+#pragma unroll
+  for (int ti = 0; ti < NTI; ++ti) {
+#pragma unroll
+    for (int to = TO0; to < TO1; ++to) {
+      const f32x4 a = Wp[(to * NTI + ti) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int c = 0; c < KT; ++c) Y[to - TO0][c] = mfma4(a[r], X[ti][c][r], Y[to - TO0][c]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting every weight read up front
+  }
+}
+
+// LayerNorm over the 128 features of each column, in place.
+//   V[t][c] holds features 16t + 4g + r of column c; gamma/beta are [128] in global/LDS.
+template <int KT>
+__device__ __forceinline__ void tile_layernorm(f32x4 (&V)[MPNN_NT][KT], const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, int lane) {
+  const int g = lane >> 4;
+  f32x4 gm[MPNN_NT], bt[MPNN_NT];
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) {
+    gm[t] = *reinterpret_cast<const f32x4*>(gamma + 16 * t + 4 * g);
+    bt[t] = *reinterpret_cast<const f32x4*>(beta + 16 * t + 4 * g);
+  }
+#pragma unroll
+  for (int c = 0; c < KT; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) s += (V[t][c].x + V[t][c].y) + (V[t][c].z + V[t][c].w);
+    const float mean = quarter_sum(s) * (1.0f / MPNN_H);
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      const f32x4 d = V[t][c] - mean;
+      q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+    const float rstd = rsqrtf(quarter_sum(q) * (1.0f / MPNN_H) + MPNN_LN_EPS);
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) V[t][c] = (V[t][c] - mean) * rstd * gm[t] + bt[t];
+  }
+}
+
+// feature vector [128] (global) -> this lane's 32 values: out[t] = v[16t + 4g .. +3]
+__device__ __forceinline__ void load_feature_row(const float* __restrict__ row, int lane, f32x4 (&out)[MPNN_NT]) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) out[t] = *reinterpret_cast<const f32x4*>(row + 16 * t + 4 * g);
+}
+
+// host-side error plumbing shared by the launchers
+extern "C" void mpnn_set_error(const char* msg);
+
+#define MPNN_CHECK_ARG(cond, msg) \
+  do {                            \
+    if (!(cond)) {                \
+      mpnn_set_error(msg);        \
+      return -1;                  \
+    }                             \
+  } while (0)
+
+#define MPNN_LAUNCH_CHECK()                 \
+  do {                                      \
+    hipError_t e__ = hipGetLastError();     \
+    if (e__ != hipSuccess) {                \
+      mpnn_set_error(hipGetErrorString(e__)); \
+      return (int)e__;                      \
+    }                                       \
+    return 0;                               \
+  } while (0)

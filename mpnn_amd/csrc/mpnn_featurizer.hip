@@ -1,0 +1,544 @@
+// Backbone featurizer kernels for gfx950 (reference: src/mpnn/models/model_utils.py
+// ProteinFeatures, :180-360).  Built with -ffp-contract=off: the neighbour search must
+// round every operation exactly like the reference's separate ATen ops do.
+#include "mpnn_common.h"
+
+// ---------------------------------------------------------------------------
+// backbone atoms: X [N,4,3] (+noise) -> atoms [N][6][4] = N, CA, C, O, CB, V (xyz + pad)
+//                                        ca_soa [B][4][L] = CA.x, CA.y, CA.z, mask
+// reference :311-330 (noise, virtual CB), :215-230 (virtual centre)
+// ---------------------------------------------------------------------------
+__global__ void k_backbone_atoms(const float* __restrict__ X, const float* __restrict__ noise,
+                                 const float* __restrict__ mask, int N, int L, float* __restrict__ atoms,
+                                 float* __restrict__ ca_soa) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float p[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    float v = X[(size_t)n * 12 + k];
+    if (noise) v = v + noise[(size_t)n * 12 + k];
+    p[k] = v;
+  }
+  const float *Nn = p, *Ca = p + 3, *C = p + 6, *O = p + 9;
+  float b[3], c[3], a[3], cb[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    b[k] = Ca[k] - Nn[k];
+    c[k] = C[k] - Ca[k];
+  }
+  a[0] = b[1] * c[2] - b[2] * c[1];
+  a[1] = b[2] * c[0] - b[0] * c[2];
+  a[2] = b[0] * c[1] - b[1] * c[0];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) cb[k] = ((-0.58273431f * a[k] + 0.56802827f * b[k]) - 0.54067466f * c[k]) + Ca[k];
+  // virtual centre (always computed; consumers ignore it unless asked)
+  float ubc[3], unc[3], pl[3], vd[3], v[3];
+  {
+    float nb = 0.f, nn = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      ubc[k] = cb[k] - Ca[k];
+      unc[k] = Nn[k] - Ca[k];
+    }
+    nb = sqrtf((ubc[0] * ubc[0] + ubc[1] * ubc[1]) + ubc[2] * ubc[2]) + 1e-6f;
+    nn = sqrtf((unc[0] * unc[0] + unc[1] * unc[1]) + unc[2] * unc[2]) + 1e-6f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      ubc[k] = ubc[k] / nb;
+      unc[k] = unc[k] / nn;
+    }
+    pl[0] = unc[1] * ubc[2] - unc[2] * ubc[1];
+    pl[1] = unc[2] * ubc[0] - unc[0] * ubc[2];
+    pl[2] = unc[0] * ubc[1] - unc[1] * ubc[0];
+    const float np_ = sqrtf((pl[0] * pl[0] + pl[1] * pl[1]) + pl[2] * pl[2]) + 1e-6f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pl[k] = pl[k] / np_;
+    vd[0] = -(pl[1] * ubc[2] - pl[2] * ubc[1]);
+    vd[1] = -(pl[2] * ubc[0] - pl[0] * ubc[2]);
+    vd[2] = -(pl[0] * ubc[1] - pl[1] * ubc[0]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = Ca[k] + 3.06f * vd[k];
+  }
+  f32x4* out = reinterpret_cast<f32x4*>(atoms + (size_t)n * 24);
+  out[0] = f32x4{Nn[0], Nn[1], Nn[2], 0.f};
+  out[1] = f32x4{Ca[0], Ca[1], Ca[2], 0.f};
+  out[2] = f32x4{C[0], C[1], C[2], 0.f};
+  out[3] = f32x4{O[0], O[1], O[2], 0.f};
+  out[4] = f32x4{cb[0], cb[1], cb[2], 0.f};
+  out[5] = f32x4{v[0], v[1], v[2], 0.f};
+  const int bb = n / L, l = n - bb * L;
+  float* so = ca_soa + (size_t)bb * 4 * L;
+  so[l] = Ca[0];
+  so[L + l] = Ca[1];
+  so[2 * L + l] = Ca[2];
+  so[3 * L + l] = mask[n];
+}
+
+// ---------------------------------------------------------------------------
+// k-NN top-k: one wavefront per query residue (reference _dist, :270-289)
+//   D      = m_i m_j sqrt(((dx^2 + dy^2) + dz^2) + 1e-6)
+//   D_adj  = D + (1 - m_i m_j) * rowmax(D)   [+ (1 - [cutoff > D]) * 1e6]
+//   output = K smallest D_adj ascending; equal values ordered by column index.
+// Selection: candidates stream through the wave 64 at a time as 64-bit keys
+// (float bits << 32 | column).  The running best-64 list lives one key per lane,
+// sorted; a chunk that cannot beat the current K-th key is skipped with one ballot,
+// otherwise it is bitonic-sorted (21 exchange stages) and bitonic-merged (7 stages).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  lo = __shfl_xor((int)lo, m);
+  hi = __shfl_xor((int)hi, m);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  lo = __shfl((int)lo, src);
+  hi = __shfl((int)hi, src);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ unsigned long long cmpxchg(unsigned long long v, int lane, int j, bool up) {
+  const unsigned long long o = shfl_xor_u64(v, j);
+  const bool lower = (lane & j) == 0;
+  const bool take_min = (lower == up);
+  const unsigned long long mn = v < o ? v : o, mx = v < o ? o : v;
+  return take_min ? mn : mx;
+}
+
+__device__ __forceinline__ unsigned long long wave_sort64(unsigned long long v, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const bool up = ((lane & k) == 0);
+      v = cmpxchg(v, lane, j, up);
+    }
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(256)
+k_knn_topk(const float* __restrict__ ca_soa, int B, int L, int K, int Kp, int has_cutoff, float cutoff,
+           long long* __restrict__ E_idx64, int* __restrict__ E_idx32, float* __restrict__ D_nb,
+           float* __restrict__ edge_mask) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // global residue
+  if (row >= B * L) return;
+  const int b = row / L, i = row - b * L;
+  const float* cx = ca_soa + (size_t)b * 4 * L;
+  const float *cy = cx + L, *cz = cx + 2 * L, *cm = cx + 3 * L;
+  const float xi = cx[i], yi = cy[i], zi = cz[i], mi = cm[i];
+
+  // pass 1: row maximum of the masked distances
+  float dmax = 0.f;
+  for (int j0 = 0; j0 < L; j0 += 64) {
+    const int j = j0 + lane;
+    if (j < L) {
+      const float dx = cx[j] - xi, dy = cy[j] - yi, dz = cz[j] - zi;
+      const float d = (mi * cm[j]) * sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
+      dmax = fmaxf(dmax, d);
+    }
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, m));
+
+  // pass 2: streaming selection
+  unsigned long long best = ~0ull;  // sorted ascending over lanes
+  for (int j0 = 0; j0 < L; j0 += 64) {
+    const int j = j0 + lane;
+    unsigned long long key = ~0ull;
+    if (j < L) {
+      const float dx = cx[j] - xi, dy = cy[j] - yi, dz = cz[j] - zi;
+      const float m2 = mi * cm[j];
+      const float d = m2 * sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
+      float da = d + (1.0f - m2) * dmax;
+      if (has_cutoff) da = da + (1.0f - (cutoff > d ? 1.0f : 0.0f)) * 1e6f;
+      key = ((unsigned long long)__float_as_uint(da) << 32) | (unsigned)j;
+    }
+    const unsigned long long thr = shfl_u64(best, K - 1);
+    if (__ballot(key < thr) == 0ull) continue;
+    key = wave_sort64(key, lane);
+    const unsigned long long rev = shfl_u64(key, 63 - lane);
+    best = best < rev ? best : rev;  // bitonic: holds the 64 smallest of the union
+#pragma unroll
+    for (int jj = 32; jj > 0; jj >>= 1) best = cmpxchg(best, lane, jj, true);
+  }
+  const float dsel = __uint_as_float((unsigned)(best >> 32));
+  const int jsel = (int)(unsigned)(best & 0xffffffffu);
+  if (lane < K) {
+    if (E_idx64) E_idx64[(size_t)row * K + lane] = jsel;
+    if (D_nb) D_nb[(size_t)row * K + lane] = dsel;
+    if (edge_mask) edge_mask[(size_t)row * K + lane] = (dsel < cutoff) ? 1.0f : 0.0f;
+  }
+  // internal index list, padded to a multiple of 16 with the residue itself (always in range)
+  if (lane < Kp) E_idx32[(size_t)row * Kp + lane] = lane < K ? jsel : i;
+}
+
+// ---------------------------------------------------------------------------
+// occupancy: log1p sum_{j != i, valid, d2 < r2} exp(-d2 / (2 (r/3)^2)) on V-V distances
+// one wavefront per residue (reference _compute_occupancy, :232-268)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_occupancy(const float* __restrict__ atoms, const float* __restrict__ mask, int B, int L, float cutoff,
+            float* __restrict__ occ) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= B * L) return;
+  const int b = row / L, i = row - b * L;
+  const f32x4 vi = reinterpret_cast<const f32x4*>(atoms + (size_t)row * 24)[5];
+  const float mi = mask[row];
+  const float r2 = cutoff * cutoff;
+  const float sigma = cutoff / 3.0f;
+  const float denom = 2.0f * (sigma * sigma);
+  float acc = 0.f;
+  for (int j = lane; j < L; j += 64) {
+    const size_t nj = (size_t)b * L + j;
+    const f32x4 vj = reinterpret_cast<const f32x4*>(atoms + nj * 24)[5];
+    const float dx = vi.x - vj.x, dy = vi.y - vj.y, dz = vi.z - vj.z;
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    const float w = (mi * mask[nj]) * (j != i ? 1.0f : 0.0f) * (d2 < r2 ? 1.0f : 0.0f);
+    acc += expf(-d2 / denom) * w;
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+  if (lane == 0) occ[row] = log1pf(acc);
+}
+
+// ---------------------------------------------------------------------------
+// weight packing (see mpnn_common.h): W[out, ld] columns [col0, col0 + in) ->
+//   packed[to][ti][lane][r] = W[16 to + (lane&15)][col0 + 16 ti + 4 (lane>>4) + r]
+// rows/cols beyond (out_f, in_f) are zero-filled (out_f, in_f need not be multiples of 16)
+// ---------------------------------------------------------------------------
+__global__ void k_pack_linear(const float* __restrict__ W, int out_f, int in_f, int ld, int col0,
+                              float* __restrict__ packed, int nto, int nti) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one float4 each
+  if (idx >= nto * nti * 64) return;
+  const int lane = idx & 63, ti = (idx >> 6) % nti, to = (idx >> 6) / nti;
+  const int row = 16 * to + (lane & 15);
+  f32x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int col = 16 * ti + 4 * (lane >> 4) + r;
+    v[r] = (row < out_f && col < in_f) ? W[(size_t)row * ld + col0 + col] : 0.f;
+  }
+  reinterpret_cast<f32x4*>(packed)[idx] = v;
+}
+
+// positional table: T[d][p] = W[p][d] + b[p]   (one_hot(d) @ W^T + b, :168-177)
+__global__ void k_pos_table(const float* __restrict__ W, const float* __restrict__ bias, int nbuckets, int npos,
+                            float* __restrict__ T) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nbuckets * npos) return;
+  const int d = idx / npos, p = idx - d * npos;
+  T[idx] = W[p * nbuckets + d] + bias[p];
+}
+
+// ---------------------------------------------------------------------------
+// edge features: one wavefront per residue, KT column tiles of 16 neighbours.
+//   B operand generated on the fly:  k-tile 0 = positional table row (16 values),
+//   k-tile 1 + a1*A + a2 = 16 RBFs of |atom_a1(i) - atom_a2(j)|   (:344-347 product order)
+//   E   = LayerNorm(W_emb . feat)            (:357-359)
+//   h_E = W_e . E + b_e                      (:464)
+// A operands (packed W_emb, W_e) stream from L2; outputs: hE in fragment layout and,
+// optionally, E in the reference's natural [N,K,128] layout.
+// ---------------------------------------------------------------------------
+template <int KT, int A>
+__global__ void __launch_bounds__(256)
+k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, const long long* __restrict__ residue_idx,
+                const long long* __restrict__ chain_labels, const float* __restrict__ pos_table,
+                const float* __restrict__ rbf_mu, const f32x4* __restrict__ Wemb, const float* __restrict__ ln_w,
+                const float* __restrict__ ln_b, const f32x4* __restrict__ We, const float* __restrict__ be, int N,
+                int L, int K, float* __restrict__ E_nat, float* __restrict__ hE) {
+  constexpr int NTI = 1 + A * A;
+  const int lane = threadIdx.x & 63;
+  const int node = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (node >= N) return;
+  const int g = lane >> 4, col = lane & 15;
+  const int b = node / L;
+  const int Kp = KT * 16;
+
+  int jn[KT];  // neighbour node (global index)
+#pragma unroll
+  for (int c = 0; c < KT; ++c) jn[c] = b * L + E_idx[(size_t)node * Kp + 16 * c + col];
+
+  f32x4 acc[MPNN_NT][KT];
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+    for (int c = 0; c < KT; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- k-tile 0: positional encodings
+  {
+    const long long ri = residue_idx[node], ci = chain_labels[node];
+    f32x4 x[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      const long long off = ri - residue_idx[jn[c]];
+      const bool same = (ci - chain_labels[jn[c]]) == 0;
+      long long d = off + 32;
+      d = d < 0 ? 0 : (d > 64 ? 64 : d);
+      if (!same) d = 65;
+      x[c] = *reinterpret_cast<const f32x4*>(pos_table + d * 16 + 4 * g);
+    }
+#pragma unroll
+    for (int to = 0; to < MPNN_NT; ++to) {
+      const f32x4 a = Wemb[(to * NTI + 0) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) acc[to][c] = mfma4(a[r], x[c][r], acc[to][c]);
+    }
+  }
+  // ---- k-tiles 1..A*A: RBFs
+  float mu[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) mu[r] = rbf_mu[4 * g + r];
+  f32x4 Bj[A][KT];
+#pragma unroll
+  for (int a2 = 0; a2 < A; ++a2)
+#pragma unroll
+    for (int c = 0; c < KT; ++c) Bj[a2][c] = reinterpret_cast<const f32x4*>(atoms + (size_t)jn[c] * 24)[a2];
+
+  for (int a1 = 0; a1 < A; ++a1) {
+    const f32x4 Ai = reinterpret_cast<const f32x4*>(atoms + (size_t)node * 24)[a1];
+#pragma unroll
+    for (int a2 = 0; a2 < A; ++a2) {
+      const int ti = 1 + a1 * A + a2;
+      f32x4 x[KT];
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        const float dx = Ai.x - Bj[a2][c].x, dy = Ai.y - Bj[a2][c].y, dz = Ai.z - Bj[a2][c].z;
+        const float d = sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float z = (d - mu[r]) / 1.25f;
+          x[c][r] = expf(-(z * z));
+        }
+      }
+#pragma unroll
+      for (int to = 0; to < MPNN_NT; ++to) {
+        const f32x4 a = Wemb[(to * NTI + ti) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < KT; ++c) acc[to][c] = mfma4(a[r], x[c][r], acc[to][c]);
+      }
+    }
+  }
+  // ---- LayerNorm over features (norm_edges)
+  tile_layernorm<KT>(acc, ln_w, ln_b, lane);
+  if (E_nat) {
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      const int e = 16 * c + col;
+      if (e < K) {
+        float* dst = E_nat + ((size_t)node * K + e) * MPNN_H + 4 * g;
+#pragma unroll
+        for (int t = 0; t < MPNN_NT; ++t) *reinterpret_cast<f32x4*>(dst + 16 * t) = acc[t][c];
+      }
+    }
+  }
+  // ---- h_E = W_e E + b
+  f32x4* out = reinterpret_cast<f32x4*>(hE) + (size_t)node * (MPNN_NT * KT * 64);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f32x4 y[4][KT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(be + 16 * (4 * half + t) + 4 * g);
+#pragma unroll
+      for (int c = 0; c < KT; ++c) y[t][c] = bb;
+    }
+    if (half == 0)
+      tile_gemm<KT, MPNN_NT, 0, 4>(We, lane, acc, y);
+    else
+      tile_gemm<KT, MPNN_NT, 4, 8>(We, lane, acc, y);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) out[((4 * half + t) * KT + c) * 64 + lane] = y[t][c];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// fragment layout <-> natural layout converters (API surfaces that expose h_E)
+// ---------------------------------------------------------------------------
+__global__ void k_frag_to_natural(const float* __restrict__ hE, int N, int K, int KT, float* __restrict__ nat) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of the fragment tensor
+  const size_t total = (size_t)N * MPNN_NT * KT * 64;
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  const size_t q = idx >> 6;
+  const int c = q % KT, t = (q / KT) % MPNN_NT;
+  const size_t node = q / ((size_t)KT * MPNN_NT);
+  const int e = 16 * c + (lane & 15);
+  if (e >= K) return;
+  const f32x4 v = reinterpret_cast<const f32x4*>(hE)[idx];
+  *reinterpret_cast<f32x4*>(nat + (node * K + e) * MPNN_H + 16 * t + 4 * (lane >> 4)) = v;
+}
+
+__global__ void k_natural_to_frag(const float* __restrict__ nat, int N, int K, int KT, float* __restrict__ hE) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)N * MPNN_NT * KT * 64;
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  const size_t q = idx >> 6;
+  const int c = q % KT, t = (q / KT) % MPNN_NT;
+  const size_t node = q / ((size_t)KT * MPNN_NT);
+  const int e = 16 * c + (lane & 15);
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (e < K) v = *reinterpret_cast<const f32x4*>(nat + (node * K + e) * MPNN_H + 16 * t + 4 * (lane >> 4));
+  reinterpret_cast<f32x4*>(hE)[idx] = v;
+}
+
+// ---------------------------------------------------------------------------
+// decoding order -> rank (inverse permutation) and the causal masks (:485-519)
+//   mask_bw[i,k] = m_i [rank_j < rank_i] (em_ik),  mask_fw[i,k] = m_i (1 - [..]) (em_ik)
+// ---------------------------------------------------------------------------
+__global__ void k_order_rank(const long long* __restrict__ order, int B, int L, int* __restrict__ rank) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * L) return;
+  const int b = idx / L, pos = idx - b * L;
+  const long long q = order[idx];
+  if (q >= 0 && q < L) rank[b * L + (int)q] = pos;
+}
+
+__global__ void k_order_masks(const int* __restrict__ rank, const long long* __restrict__ E_idx64,
+                              const float* __restrict__ mask, const float* __restrict__ edge_mask, int B, int L,
+                              int K, float* __restrict__ mask_bw, float* __restrict__ mask_fw) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * L * K) return;
+  const size_t node = idx / K;
+  const int b = node / L;
+  const int j = (int)E_idx64[idx];
+  const float att = rank[node] > rank[b * L + j] ? 1.0f : 0.0f;
+  float bw = mask[node] * att, fw = mask[node] * (1.0f - att);
+  if (edge_mask) {
+    bw *= edge_mask[idx];
+    fw *= edge_mask[idx];
+  }
+  mask_bw[idx] = bw;
+  mask_fw[idx] = fw;
+}
+
+// ===========================================================================
+// C ABI launchers (declared in include/mpnn_hip.h)
+// ===========================================================================
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+extern "C" int mpnn_backbone_atoms(const float* X, const float* noise, const float* mask, int B, int L,
+                                   float* atoms, float* ca_soa, void* stream) {
+  MPNN_CHECK_ARG(X && mask && atoms && ca_soa && B > 0 && L > 0, "mpnn_backbone_atoms: bad arguments");
+  const int N = B * L;
+  hipLaunchKernelGGL(k_backbone_atoms, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, X, noise, mask, N,
+                     L, atoms, ca_soa);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_knn_topk(const float* ca_soa, int B, int L, int K, float edge_cutoff, int64_t* E_idx64,
+                             int32_t* E_idx32, float* D_neighbors, float* edge_mask, void* stream) {
+  MPNN_CHECK_ARG(ca_soa && E_idx32 && B > 0 && L > 0, "mpnn_knn_topk: bad arguments");
+  MPNN_CHECK_ARG(K >= 1 && K <= 64 && K <= L, "mpnn_knn_topk: K must satisfy 1 <= K <= min(64, L)");
+  const int Kp = 16 * ((K + 15) / 16);
+  const int has_cut = edge_cutoff > 0.f;
+  MPNN_CHECK_ARG(has_cut || !edge_mask, "mpnn_knn_topk: edge_mask requested without a cutoff");
+  hipLaunchKernelGGL(k_knn_topk, dim3(ceil_div((long long)B * L, 4)), dim3(256), 0, (hipStream_t)stream, ca_soa, B, L,
+                     K, Kp, has_cut, edge_cutoff, (long long*)E_idx64, E_idx32, D_neighbors, edge_mask);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_occupancy(const float* atoms, const float* mask, int B, int L, float cutoff, float* occ,
+                              void* stream) {
+  MPNN_CHECK_ARG(atoms && mask && occ && B > 0 && L > 0 && cutoff > 0.f, "mpnn_occupancy: bad arguments");
+  hipLaunchKernelGGL(k_occupancy, dim3(ceil_div((long long)B * L, 4)), dim3(256), 0, (hipStream_t)stream, atoms, mask,
+                     B, L, cutoff, occ);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_pack_linear(const float* W, int out_f, int in_f, int ld, int col0, float* packed, void* stream) {
+  MPNN_CHECK_ARG(W && packed && out_f > 0 && in_f > 0 && ld >= col0 + in_f, "mpnn_pack_linear: bad arguments");
+  const int nto = (out_f + 15) / 16, nti = (in_f + 15) / 16;
+  hipLaunchKernelGGL(k_pack_linear, dim3(ceil_div((long long)nto * nti * 64, 256)), dim3(256), 0, (hipStream_t)stream,
+                     W, out_f, in_f, ld, col0, packed, nto, nti);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_pos_table(const float* W, const float* bias, int nbuckets, int npos, float* table, void* stream) {
+  MPNN_CHECK_ARG(W && bias && table && nbuckets == 66 && npos == 16, "mpnn_pos_table: expects a 16x66 linear");
+  hipLaunchKernelGGL(k_pos_table, dim3(ceil_div(nbuckets * npos, 256)), dim3(256), 0, (hipStream_t)stream, W, bias,
+                     nbuckets, npos, table);
+  MPNN_LAUNCH_CHECK();
+}
+
+template <int KT>
+static int launch_edge_features(int A, const float* atoms, const int* E_idx, const long long* ridx,
+                                const long long* chain, const float* pos_table, const float* rbf_mu,
+                                const float* Wemb, const float* ln_w, const float* ln_b, const float* We,
+                                const float* be, int N, int L, int K, float* E_nat, float* hE, hipStream_t s) {
+  dim3 grid(ceil_div(N, 4)), block(256);
+  if (A == 5)
+    hipLaunchKernelGGL((k_edge_features<KT, 5>), grid, block, 0, s, atoms, E_idx, ridx, chain, pos_table, rbf_mu,
+                       (const f32x4*)Wemb, ln_w, ln_b, (const f32x4*)We, be, N, L, K, E_nat, hE);
+  else
+    hipLaunchKernelGGL((k_edge_features<KT, 6>), grid, block, 0, s, atoms, E_idx, ridx, chain, pos_table, rbf_mu,
+                       (const f32x4*)Wemb, ln_w, ln_b, (const f32x4*)We, be, N, L, K, E_nat, hE);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_edge_features(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
+                                  const int64_t* chain_labels, const float* pos_table, const float* rbf_mu,
+                                  const float* Wemb_packed, const float* ln_w, const float* ln_b,
+                                  const float* We_packed, const float* We_bias, int B, int L, int K, int n_atoms,
+                                  float* E_natural, float* hE_frag, void* stream) {
+  MPNN_CHECK_ARG(atoms && E_idx32 && residue_idx && chain_labels && pos_table && rbf_mu && Wemb_packed && ln_w &&
+                     ln_b && We_packed && We_bias && hE_frag,
+                 "mpnn_edge_features: null pointer");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64, "mpnn_edge_features: need 1 <= K <= 64");
+  MPNN_CHECK_ARG(n_atoms == 5 || n_atoms == 6, "mpnn_edge_features: n_atoms must be 5 or 6");
+  const int KT = (K + 15) / 16, N = B * L;
+  hipStream_t s = (hipStream_t)stream;
+  const long long *ri = (const long long*)residue_idx, *cl = (const long long*)chain_labels;
+  switch (KT) {
+    case 1: return launch_edge_features<1>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, E_natural, hE_frag, s);
+    case 2: return launch_edge_features<2>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, E_natural, hE_frag, s);
+    case 3: return launch_edge_features<3>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, E_natural, hE_frag, s);
+    default: return launch_edge_features<4>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, E_natural, hE_frag, s);
+  }
+}
+
+extern "C" int mpnn_edges_to_natural(const float* hE_frag, int n_nodes, int K, float* natural, void* stream) {
+  MPNN_CHECK_ARG(hE_frag && natural && n_nodes > 0 && K >= 1 && K <= 64, "mpnn_edges_to_natural: bad arguments");
+  const int KT = (K + 15) / 16;
+  const long long total = (long long)n_nodes * MPNN_NT * KT * 64;
+  hipLaunchKernelGGL(k_frag_to_natural, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, hE_frag,
+                     n_nodes, K, KT, natural);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_edges_from_natural(const float* natural, int n_nodes, int K, float* hE_frag, void* stream) {
+  MPNN_CHECK_ARG(hE_frag && natural && n_nodes > 0 && K >= 1 && K <= 64, "mpnn_edges_from_natural: bad arguments");
+  const int KT = (K + 15) / 16;
+  const long long total = (long long)n_nodes * MPNN_NT * KT * 64;
+  hipLaunchKernelGGL(k_natural_to_frag, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, natural,
+                     n_nodes, K, KT, hE_frag);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_order_rank(const int64_t* order, int B, int L, int32_t* rank, void* stream) {
+  MPNN_CHECK_ARG(order && rank && B > 0 && L > 0, "mpnn_order_rank: bad arguments");
+  hipLaunchKernelGGL(k_order_rank, dim3(ceil_div((long long)B * L, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)order, B, L, rank);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_order_masks(const int32_t* rank, const int64_t* E_idx64, const float* mask,
+                                const float* edge_mask, int B, int L, int K, float* mask_bw, float* mask_fw,
+                                void* stream) {
+  MPNN_CHECK_ARG(rank && E_idx64 && mask && mask_bw && mask_fw && B > 0 && L > 0 && K > 0,
+                 "mpnn_order_masks: bad arguments");
+  hipLaunchKernelGGL(k_order_masks, dim3(ceil_div((long long)B * L * K, 256)), dim3(256), 0, (hipStream_t)stream, rank,
+                     (const long long*)E_idx64, mask, edge_mask, B, L, K, mask_bw, mask_fw);
+  MPNN_LAUNCH_CHECK();
+}

@@ -1,0 +1,446 @@
+"""Host-side orchestration of the gfx950 kernels (one HIP stream, no host syncs).
+
+Data layout in HBM (fp32; N = B*L residues, K' = min(k, L), KT = ceil(K'/16)):
+  atoms   [N][6][4]        backbone + virtual atoms
+  ca_soa  [B][4][L]        CA coordinates + mask, structure-of-arrays for the k-NN sweep
+  E_idx32 [N][16 KT]       neighbour list (int32, padded with self)
+  hE      [N][8][KT][64][4] edge features in MFMA fragment layout (never [B,L,K,128] on the hot path)
+  hV      [N][128]         node features
+  PQ      [N][128 nproj]   per-node projections consumed by the next edge kernel
+  gsum    [N][128], cnt[N] masked neighbour sums of the message MLP's second layer
+Nothing of size [B,L,L] or [B,L,K,384/512] is ever materialised.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream_ptr
+
+H = 128
+
+
+def _require_device(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"mpnn_amd: `{name}` must be on a ROCm device (got {t.device}); "
+                           "the HIP path has no CPU fallback")
+
+
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _i64(t):
+    return t.detach().to(torch.int64).contiguous()
+
+
+# ---------------------------------------------------------------------------
+# weight packing (cached on the module; rebuilt when any parameter changes)
+# ---------------------------------------------------------------------------
+class PackedWeights:
+    def __init__(self, model):
+        self.key = self.make_key(model)
+        dev = model.W_out.weight.device
+        self.dev = dev
+        st = stream_ptr()
+        self._keep = []
+
+        def pack(W, col0=0, ncols=None, out=None):
+            W = _f32(W)
+            self._keep.append(W)
+            out_f, ld = W.shape
+            ncols = ld - col0 if ncols is None else ncols
+            nto, nti = (out_f + 15) // 16, (ncols + 15) // 16
+            if out is None:
+                out = torch.empty(nto * nti * 256, device=dev, dtype=torch.float32)
+            call("mpnn_pack_linear", ptr(W), out_f, ncols, ld, col0, ptr(out), st)
+            return out
+
+        def vec(b):
+            return _f32(b)
+
+        def proj_group(blocks):
+            """blocks: list of (W, col0, bias|None) -> (packed [n][8][8][64][4], bias [n*128])."""
+            n = len(blocks)
+            if n == 0:
+                return None, None, 0
+            Wp = torch.empty(n * 4096 * 4, device=dev, dtype=torch.float32)
+            bp = torch.zeros(n * H, device=dev, dtype=torch.float32)
+            for i, (W, col0, b) in enumerate(blocks):
+                pack(W, col0, H, out=Wp[i * 16384:(i + 1) * 16384])
+                if b is not None:
+                    bp[i * H:(i + 1) * H] = _f32(b)
+            return Wp, bp, n
+
+        f = model.features
+        self.n_atoms = 6 if f.use_virtual_center else 5
+        self.pos_table = torch.empty(66 * 16, device=dev, dtype=torch.float32)
+        Wl, bl = _f32(f.embeddings.linear.weight), _f32(f.embeddings.linear.bias)
+        self._keep += [Wl, bl]
+        call("mpnn_pos_table", ptr(Wl), ptr(bl), 66, 16, ptr(self.pos_table), st)
+        self.rbf_mu = torch.linspace(2.0, 22.0, 16, device=dev, dtype=torch.float32)
+        self.Wemb = pack(f.edge_embedding.weight)
+        self.ln_e_w, self.ln_e_b = vec(f.norm_edges.weight), vec(f.norm_edges.bias)
+        self.We, self.be = pack(model.W_e.weight), vec(model.W_e.bias)
+
+        enc, dec = list(model.encoder_layers), list(model.decoder_layers)
+        self.enc, self.dec = [], []
+        for lyr in enc:
+            d = dict(W1b=pack(lyr.W1.weight, H, H), W2=pack(lyr.W2.weight), b2=vec(lyr.W2.bias),
+                     W3=pack(lyr.W3.weight), b3=vec(lyr.W3.bias),
+                     W11b=pack(lyr.W11.weight, H, H), W12=pack(lyr.W12.weight), b12=vec(lyr.W12.bias),
+                     W13=pack(lyr.W13.weight), b13=vec(lyr.W13.bias),
+                     ln1w=vec(lyr.norm1.weight), ln1b=vec(lyr.norm1.bias), ln2w=vec(lyr.norm2.weight),
+                     ln2b=vec(lyr.norm2.bias), ln3w=vec(lyr.norm3.weight), ln3b=vec(lyr.norm3.bias),
+                     Win=pack(lyr.dense.W_in.weight), bin=vec(lyr.dense.W_in.bias),
+                     Wout=pack(lyr.dense.W_out.weight), bout=vec(lyr.dense.W_out.bias), scale=float(lyr.scale))
+            self.enc.append(d)
+        for lyr in dec:
+            d = dict(W1b=pack(lyr.W1.weight, H, H), W2=pack(lyr.W2.weight), b2=vec(lyr.W2.bias),
+                     W3=pack(lyr.W3.weight), b3=vec(lyr.W3.bias),
+                     ln1w=vec(lyr.norm1.weight), ln1b=vec(lyr.norm1.bias), ln2w=vec(lyr.norm2.weight),
+                     ln2b=vec(lyr.norm2.bias),
+                     Win=pack(lyr.dense.W_in.weight), bin=vec(lyr.dense.W_in.bias),
+                     Wout=pack(lyr.dense.W_out.weight), bout=vec(lyr.dense.W_out.bias), scale=float(lyr.scale))
+            self.dec.append(d)
+
+        # projection groups: what the NEXT edge kernel needs from the node features
+        def enc_msg_blocks(l):  # P = W1a h + b1 ; Q = W1c h
+            return [(enc[l].W1.weight, 0, enc[l].W1.bias), (enc[l].W1.weight, 2 * H, None)]
+
+        def enc_upd_blocks(l):  # P' = W11a h + b11 ; Q' = W11c h
+            return [(enc[l].W11.weight, 0, enc[l].W11.bias), (enc[l].W11.weight, 2 * H, None)]
+
+        def dec_first_blocks():  # Pa_0, PV_0 (= PVenc_0), PVenc_1, ...
+            if not dec:
+                return []
+            blocks = [(dec[0].W1.weight, 0, dec[0].W1.bias)]
+            blocks += [(d_.W1.weight, 3 * H, None) for d_ in dec]
+            return blocks
+
+        def dec_next_blocks(l):
+            return [(dec[l].W1.weight, 0, dec[l].W1.bias), (dec[l].W1.weight, 3 * H, None)]
+
+        self.g_init = proj_group(enc_msg_blocks(0) if enc else dec_first_blocks())
+        self.g_enc = []
+        for l in range(len(enc)):
+            nxt = enc_msg_blocks(l + 1) if l + 1 < len(enc) else dec_first_blocks()
+            self.g_enc.append(proj_group(enc_upd_blocks(l) + nxt))
+        self.g_dec = [proj_group(dec_next_blocks(l + 1)) if l + 1 < len(dec) else (None, None, 0)
+                      for l in range(len(dec))]
+        # per-letter table TS = [W1c_0 | W1c_1 | ...] W_s^T : the sequence term of every decoder layer
+        self.n_vocab = model.W_s.weight.shape[0]
+        self.Ws = _f32(model.W_s.weight)
+        self.TS = None
+        if dec:
+            g_ts = proj_group([(d_.W1.weight, 2 * H, None) for d_ in dec])
+            self.TS = torch.empty(self.n_vocab, len(dec) * H, device=dev, dtype=torch.float32)
+            call("mpnn_node_update", ptr(self.Ws), None, None, 0.0, None, None, None, None, None, None, None, None,
+                 None, None, None, 1.0, 0, ptr(g_ts[0]), ptr(g_ts[1]), g_ts[2], self.n_vocab, None, ptr(self.TS), st)
+            self._keep.append(g_ts)
+        self.Wlogit, self.blogit = pack(model.W_out.weight), vec(model.W_out.bias)
+        self.n_letters = model.W_out.weight.shape[0]
+        self.occ = None
+        if model.occupancy_mlp is not None:
+            m = model.occupancy_mlp
+            self.occ = dict(w0=_f32(m[0].weight).reshape(-1), b0=vec(m[0].bias), W2=pack(m[2].weight),
+                            b2=vec(m[2].bias), lnw=vec(m[3].weight), lnb=vec(m[3].bias))
+
+    @staticmethod
+    def make_key(model):
+        return tuple((p.data_ptr(), p._version, str(p.device)) for p in model.parameters())
+
+
+def packed(model) -> PackedWeights:
+    pw = getattr(model, "_packed", None)
+    if pw is None or pw.key != PackedWeights.make_key(model):
+        pw = PackedWeights(model)
+        model._packed = pw
+    return pw
+
+
+# ---------------------------------------------------------------------------
+# featurizer pieces
+# ---------------------------------------------------------------------------
+def _geometry(features_mod, X, mask, backbone_noise, training):
+    """atoms, ca_soa, E_idx64, E_idx32, D_nb, edge_mask, K  (reference :311-332)."""
+    B, L = mask.shape
+    dev = X.device
+    st = stream_ptr()
+    X = _f32(X)
+    noise = None
+    if backbone_noise is not None:
+        noise = _f32(backbone_noise)
+    elif training and features_mod.augment_eps > 0:
+        noise = features_mod.augment_eps * torch.randn_like(X)
+    atoms = torch.empty(B * L * 24, device=dev, dtype=torch.float32)
+    ca_soa = torch.empty(B * 4 * L, device=dev, dtype=torch.float32)
+    call("mpnn_backbone_atoms", ptr(X), ptr(noise), ptr(mask), B, L, ptr(atoms), ptr(ca_soa), st)
+    K = min(int(features_mod.top_k), L)
+    Kp = 16 * ((K + 15) // 16)
+    cutoff = features_mod.edge_cutoff
+    E_idx64 = torch.empty(B, L, K, device=dev, dtype=torch.int64)
+    E_idx32 = torch.empty(B * L * Kp, device=dev, dtype=torch.int32)
+    D_nb = torch.empty(B, L, K, device=dev, dtype=torch.float32)
+    edge_mask = torch.empty(B, L, K, device=dev, dtype=torch.float32) if cutoff is not None else None
+    call("mpnn_knn_topk", ptr(ca_soa), B, L, K, float(cutoff) if cutoff is not None else 0.0, ptr(E_idx64),
+         ptr(E_idx32), ptr(D_nb), ptr(edge_mask), st)
+    return atoms, ca_soa, E_idx64, E_idx32, D_nb, edge_mask, K
+
+
+def _edge_features(pw, atoms, E_idx32, residue_idx, chain_labels, B, L, K, want_E):
+    dev = atoms.device
+    KT = (K + 15) // 16
+    hE = torch.empty(B * L * 8 * KT * 256, device=dev, dtype=torch.float32)
+    E_nat = torch.empty(B, L, K, H, device=dev, dtype=torch.float32) if want_E else None
+    call("mpnn_edge_features", ptr(atoms), ptr(E_idx32), ptr(residue_idx), ptr(chain_labels), ptr(pw.pos_table),
+         ptr(pw.rbf_mu), ptr(pw.Wemb), ptr(pw.ln_e_w), ptr(pw.ln_e_b), ptr(pw.We), ptr(pw.be), B, L, K, pw.n_atoms,
+         ptr(E_nat), ptr(hE), stream_ptr())
+    return hE, E_nat
+
+
+def _occupancy(features_mod, atoms, mask, B, L):
+    if features_mod.occupancy_cutoff is None:
+        return None
+    occ = torch.empty(B, L, 1, device=atoms.device, dtype=torch.float32)
+    call("mpnn_occupancy", ptr(atoms), ptr(mask), B, L, float(features_mod.occupancy_cutoff), ptr(occ), stream_ptr())
+    return occ
+
+
+def _find_owner(features_mod):
+    owner = getattr(features_mod, "_owner", None)
+    return owner() if owner is not None else None
+
+
+def features_standalone(features_mod, X, mask, residue_idx, chain_labels, backbone_noise=None):
+    """ProteinFeatures.forward surface (reference :309-360): returns the natural-layout E."""
+    _require_device(X, "X")
+    mask = _f32(mask)
+    B, L = mask.shape
+    pw = _FeaturePack.get(features_mod)
+    atoms, _, E_idx64, E_idx32, _, edge_mask, K = _geometry(features_mod, X, mask, backbone_noise,
+                                                            features_mod.training)
+    occ = _occupancy(features_mod, atoms, mask, B, L)
+    _, E_nat = _edge_features(pw, atoms, E_idx32, _i64(residue_idx), _i64(chain_labels), B, L, K, True)
+    return E_nat, E_idx64, occ, edge_mask
+
+
+class _FeaturePack:
+    """Packed weights for a stand-alone ProteinFeatures call (W_e is not part of that module, so an
+    identity-free dummy is used and only E is consumed)."""
+
+    @staticmethod
+    def get(fm):
+        key = tuple((p.data_ptr(), p._version) for p in fm.parameters())
+        c = getattr(fm, "_packed", None)
+        if c is not None and c.key == key:
+            return c
+        c = _FeaturePack()
+        c.key = key
+        dev = fm.edge_embedding.weight.device
+        st = stream_ptr()
+        c.n_atoms = 6 if fm.use_virtual_center else 5
+        c.pos_table = torch.empty(66 * 16, device=dev, dtype=torch.float32)
+        Wl, bl = _f32(fm.embeddings.linear.weight), _f32(fm.embeddings.linear.bias)
+        call("mpnn_pos_table", ptr(Wl), ptr(bl), 66, 16, ptr(c.pos_table), st)
+        c.rbf_mu = torch.linspace(2.0, 22.0, 16, device=dev, dtype=torch.float32)
+        W = _f32(fm.edge_embedding.weight)
+        nti = (W.shape[1] + 15) // 16
+        c.Wemb = torch.empty(8 * nti * 256, device=dev, dtype=torch.float32)
+        call("mpnn_pack_linear", ptr(W), H, W.shape[1], W.shape[1], 0, ptr(c.Wemb), st)
+        c.ln_e_w, c.ln_e_b = _f32(fm.norm_edges.weight), _f32(fm.norm_edges.bias)
+        c.We = torch.zeros(8 * 8 * 256, device=dev, dtype=torch.float32)
+        c.be = torch.zeros(H, device=dev, dtype=torch.float32)
+        c._keep = (Wl, bl, W)
+        fm._packed = c
+        return c
+
+
+# ---------------------------------------------------------------------------
+# node kernel wrapper
+# ---------------------------------------------------------------------------
+def _node_update(hV_in, n_nodes, lw, gsum, cnt, cnt_const, mask, group, hV_out, PQ):
+    Wp, bp, nproj = group
+    if lw is None:
+        call("mpnn_node_update", ptr(hV_in), None, None, 0.0, None, None, None, None, None, None, None, None, None,
+             None, None, 1.0, 0, ptr(Wp), ptr(bp), nproj, n_nodes, None, ptr(PQ), stream_ptr())
+    else:
+        call("mpnn_node_update", ptr(hV_in), ptr(gsum), ptr(cnt), float(cnt_const), ptr(mask), ptr(lw["W3"]),
+             ptr(lw["b3"]), ptr(lw["ln1w"]), ptr(lw["ln1b"]), ptr(lw["Win"]), ptr(lw["bin"]), ptr(lw["Wout"]),
+             ptr(lw["bout"]), ptr(lw["ln2w"]), ptr(lw["ln2b"]), lw["scale"], 1, ptr(Wp), ptr(bp), nproj, n_nodes,
+             ptr(hV_out), ptr(PQ), stream_ptr())
+
+
+# ---------------------------------------------------------------------------
+# full forward
+# ---------------------------------------------------------------------------
+def forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order=None, fix_backbone_noise=None,
+            return_intermediates: bool = False):
+    """ProteinMPNN.forward (reference :427-529) on the HIP kernels.  Inference only for now:
+    the backward kernels are not built yet, so a grad-requiring call fails loudly."""
+    _require_device(X, "X")
+    if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()) and model.training:
+        raise NotImplementedError("mpnn_amd: backward kernels are not built yet; call under torch.no_grad() / eval()")
+    dev = X.device
+    mask = _f32(mask)
+    B, L = mask.shape
+    N = B * L
+    S = _i64(S)
+    residue_idx, chain_labels = _i64(residue_idx), _i64(chain_encoding_all)
+    pw = packed(model)
+    st = stream_ptr()
+    fm = model.features
+    inter = {}
+
+    atoms, _, E_idx64, E_idx32, D_nb, edge_mask, K = _geometry(fm, X, mask, fix_backbone_noise, model.training)
+    occ = _occupancy(fm, atoms, mask, B, L)
+    hE, _ = _edge_features(pw, atoms, E_idx32, residue_idx, chain_labels, B, L, K, False)
+
+    hV = torch.zeros(N, H, device=dev, dtype=torch.float32)
+    if pw.occ is not None and occ is not None:
+        o = pw.occ
+        call("mpnn_occupancy_mlp", ptr(occ), ptr(o["w0"]), ptr(o["b0"]), ptr(o["W2"]), ptr(o["b2"]), ptr(o["lnw"]),
+             ptr(o["lnb"]), N, ptr(hV), st)
+    if return_intermediates:
+        inter.update(E_idx=E_idx64, D_neighbors=D_nb, edge_mask=edge_mask, occupancy=occ, h_V_enc=[], h_V_dec=[],
+                     h_E_enc=[])
+        inter["h_E0"] = edges_to_natural(hE, N, K).view(B, L, K, H)
+
+    gsum = torch.empty(N, H, device=dev, dtype=torch.float32)
+    cnt = torch.empty(N, device=dev, dtype=torch.float32)
+
+    def new_pq(group):
+        return torch.empty(N, max(group[2], 1) * H, device=dev, dtype=torch.float32) if group[2] else None
+
+    PQ = new_pq(pw.g_init)
+    if pw.g_init[2]:
+        _node_update(hV, N, None, None, None, 0.0, None, pw.g_init, None, PQ)
+
+    n_enc, n_dec = len(pw.enc), len(pw.dec)
+    for l, lw in enumerate(pw.enc):
+        ld = PQ.shape[1]
+        offP, offQ = (0, H) if l == 0 else (2 * H, 3 * H)
+        call("mpnn_enc_message", ptr(hE), ptr(PQ), ld, offP, offQ, ptr(E_idx32), ptr(mask), ptr(edge_mask),
+             ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"]), B, L, K, ptr(gsum), ptr(cnt), st)
+        grp = pw.g_enc[l]
+        PQn = new_pq(grp)
+        hVn = torch.empty_like(hV)
+        _node_update(hV, N, lw, gsum, cnt, 0.0, mask, grp, hVn, PQn)
+        hV, PQ = hVn, PQn
+        call("mpnn_enc_edge_update", ptr(hE), ptr(PQ), PQ.shape[1], 0, H, ptr(E_idx32), ptr(lw["W11b"]),
+             ptr(lw["W12"]), ptr(lw["b12"]), ptr(lw["W13"]), ptr(lw["b13"]), ptr(lw["ln3w"]), ptr(lw["ln3b"]), B, L, K,
+             st)
+        if return_intermediates:
+            inter["h_V_enc"].append(hV.view(B, L, H))
+            inter["h_E_enc"].append(edges_to_natural(hE, N, K).view(B, L, K, H))
+
+    # ---- decoder
+    if n_dec:
+        chain_M = _f32(chain_M) * mask
+        if fix_order is not None:
+            order = _i64(fix_order)
+        else:
+            # reference :489-491 (random decoding order; the argsort of a [B,L] key is host-side plumbing)
+            order = torch.argsort((chain_M + 0.0001) * torch.abs(torch.randn(chain_M.shape, device=dev)))
+        rank = torch.zeros(N, device=dev, dtype=torch.int32)
+        call("mpnn_order_rank", ptr(order), B, L, ptr(rank), st)
+        if return_intermediates:
+            bw = torch.empty(B, L, K, device=dev, dtype=torch.float32)
+            fw = torch.empty_like(bw)
+            call("mpnn_order_masks", ptr(rank), ptr(E_idx64), ptr(mask), ptr(edge_mask), B, L, K, ptr(bw), ptr(fw), st)
+            inter.update(mask_bw=bw, mask_fw=fw, order=order)
+        # PQ layout after the last encoder stage (or g_init when there is no encoder):
+        #   [P'|Q'|Pa_0|PV_0|PVenc_1|...] with encoder, [Pa_0|PV_0|PVenc_1|...] without
+        base = 2 * H if n_enc else 0
+        PQenc = PQ
+        ldenc = PQenc.shape[1]
+        PQd, offPa, offPV = PQenc, base, base + H
+        for l, lw in enumerate(pw.dec):
+            call("mpnn_dec_message", ptr(hE), ptr(PQd), PQd.shape[1], offPa, offPV, ptr(PQenc), ldenc,
+                 base + H * (1 + l), ptr(pw.TS), pw.TS.shape[1], H * l, ptr(S), ptr(rank), ptr(E_idx32), ptr(mask),
+                 ptr(edge_mask), ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"]), B, L, K, ptr(gsum), st)
+            grp = pw.g_dec[l]
+            PQn = new_pq(grp)
+            hVn = torch.empty_like(hV)
+            _node_update(hV, N, lw, gsum, None, float(K), mask, grp, hVn, PQn)
+            hV = hVn
+            if PQn is not None:
+                PQd, offPa, offPV = PQn, 0, H
+            if return_intermediates:
+                inter["h_V_dec"].append(hV.view(B, L, H))
+
+    log_probs = torch.empty(B, L, pw.n_letters, device=dev, dtype=torch.float32)
+    call("mpnn_logits_log_softmax", ptr(hV), ptr(pw.Wlogit), ptr(pw.blogit), pw.n_letters, N, ptr(log_probs), st)
+    if return_intermediates:
+        inter["log_probs"] = log_probs
+        return inter
+    return log_probs
+
+
+def edges_to_natural(hE, n_nodes, K):
+    out = torch.empty(n_nodes, K, H, device=hE.device, dtype=torch.float32)
+    call("mpnn_edges_to_natural", ptr(hE), n_nodes, K, ptr(out), stream_ptr())
+    return out
+
+
+def edges_from_natural(h_E_nat, n_nodes, K):
+    KT = (K + 15) // 16
+    out = torch.empty(n_nodes * 8 * KT * 256, device=h_E_nat.device, dtype=torch.float32)
+    call("mpnn_edges_from_natural", ptr(h_E_nat), n_nodes, K, ptr(out), stream_ptr())
+    return out
+
+
+# ---------------------------------------------------------------------------
+# stand-alone EncLayer surface (reference :73-95): natural layouts in and out
+# ---------------------------------------------------------------------------
+def enc_layer_standalone(layer, h_V, h_E, E_idx, mask_V=None, mask_attend=None):
+    _require_device(h_V, "h_V")
+    dev = h_V.device
+    B, L, K = E_idx.shape
+    N = B * L
+    st = stream_ptr()
+    key = tuple((p.data_ptr(), p._version) for p in layer.parameters())
+    c = getattr(layer, "_packed", None)
+    if c is None or c["key"] != key:
+        def pack(W, col0=0, ncols=None):
+            W = _f32(W)
+            out_f, ld = W.shape
+            ncols = ld - col0 if ncols is None else ncols
+            out = torch.empty(((out_f + 15) // 16) * ((ncols + 15) // 16) * 256, device=dev, dtype=torch.float32)
+            call("mpnn_pack_linear", ptr(W), out_f, ncols, ld, col0, ptr(out), st)
+            return out
+        Wp = torch.cat([pack(layer.W1.weight, 0, H), pack(layer.W1.weight, 2 * H, H)])
+        bp = torch.cat([_f32(layer.W1.bias), torch.zeros(H, device=dev)])
+        Wp2 = torch.cat([pack(layer.W11.weight, 0, H), pack(layer.W11.weight, 2 * H, H)])
+        bp2 = torch.cat([_f32(layer.W11.bias), torch.zeros(H, device=dev)])
+        c = dict(key=key, g1=(Wp, bp, 2), g2=(Wp2, bp2, 2), W1b=pack(layer.W1.weight, H, H), W2=pack(layer.W2.weight),
+                 b2=_f32(layer.W2.bias), W3=pack(layer.W3.weight), b3=_f32(layer.W3.bias),
+                 W11b=pack(layer.W11.weight, H, H), W12=pack(layer.W12.weight), b12=_f32(layer.W12.bias),
+                 W13=pack(layer.W13.weight), b13=_f32(layer.W13.bias), ln1w=_f32(layer.norm1.weight),
+                 ln1b=_f32(layer.norm1.bias), ln2w=_f32(layer.norm2.weight), ln2b=_f32(layer.norm2.bias),
+                 ln3w=_f32(layer.norm3.weight), ln3b=_f32(layer.norm3.bias), Win=pack(layer.dense.W_in.weight),
+                 bin=_f32(layer.dense.W_in.bias), Wout=pack(layer.dense.W_out.weight),
+                 bout=_f32(layer.dense.W_out.bias), scale=float(layer.scale))
+        layer._packed = c
+    hV = _f32(h_V).view(N, H)
+    hE = edges_from_natural(_f32(h_E), N, K)
+    Kp = 16 * ((K + 15) // 16)
+    idx32 = torch.arange(L, device=dev, dtype=torch.int32).view(1, L, 1).expand(B, L, Kp).contiguous()
+    idx32[:, :, :K] = E_idx.to(torch.int32)
+    ones = torch.ones(N, device=dev, dtype=torch.float32)
+    m_att = _f32(mask_attend) if mask_attend is not None else None
+    m_V = _f32(mask_V).reshape(N) if mask_V is not None else ones
+    PQ = torch.empty(N, 2 * H, device=dev, dtype=torch.float32)
+    _node_update(hV, N, None, None, None, 0.0, None, c["g1"], None, PQ)
+    gsum = torch.empty(N, H, device=dev, dtype=torch.float32)
+    cnt = torch.empty(N, device=dev, dtype=torch.float32)
+    call("mpnn_enc_message", ptr(hE), ptr(PQ), 2 * H, 0, H, ptr(idx32), ptr(ones), ptr(m_att), ptr(c["W1b"]),
+         ptr(c["W2"]), ptr(c["b2"]), B, L, K, ptr(gsum), ptr(cnt), st)
+    hVn = torch.empty_like(hV)
+    PQ2 = torch.empty(N, 2 * H, device=dev, dtype=torch.float32)
+    _node_update(hV, N, c, gsum, cnt, 0.0, m_V, c["g2"], hVn, PQ2)
+    call("mpnn_enc_edge_update", ptr(hE), ptr(PQ2), 2 * H, 0, H, ptr(idx32), ptr(c["W11b"]), ptr(c["W12"]),
+         ptr(c["b12"]), ptr(c["W13"]), ptr(c["b13"]), ptr(c["ln3w"]), ptr(c["ln3b"]), B, L, K, st)
+    return hVn.view(B, L, H), edges_to_natural(hE, N, K).view(B, L, K, H)

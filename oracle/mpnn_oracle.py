@@ -69,6 +69,18 @@ def _gelu(x: Tensor) -> Tensor:
     return F.gelu(x)  # exact erf form: nn.GELU() default (:70, :115, :149)
 
 
+def _sqrt(x: Tensor) -> Tensor:
+    """IEEE-754 correctly rounded fp32 square root (computed in fp64, rounded once).
+
+    torch's CPU sqrt kernel is NOT correctly rounded (measured in the build container, torch
+    2.10 CPU, every ATEN_CPU_CAPABILITY: 0.67 % of fp32 inputs come out 1 ulp off), whereas
+    the reference's production device path (CUDA sqrtf) and this repo's HIP kernels are.  The
+    oracle follows IEEE so that "bit-exact neighbour indices" is platform independent; against
+    the CPU-generated golden vectors distances therefore agree to 1 ulp and indices agree
+    wherever two candidates are more than 2 ulp apart (tests/test_oracle_golden.py)."""
+    return torch.sqrt(x.double()).to(x.dtype)
+
+
 def take_neighbors(nodes: Tensor, E_idx: Tensor) -> Tensor:
     """nodes [B,L,C], E_idx [B,L,K] -> [B,L,K,C]   (gather_nodes, :21-30)."""
     B, L, K = E_idx.shape
@@ -113,7 +125,7 @@ def adjusted_distances(ca: Tensor, mask: Tensor, cfg: Config) -> Tensor:
     """D_adjust [B,L,L] exactly as `_dist` builds it   (:270-279)."""
     m2 = mask[:, None, :] * mask[:, :, None]
     dx = ca[:, None, :, :] - ca[:, :, None, :]
-    D = m2 * torch.sqrt(torch.sum(dx**2, 3) + 1e-6)
+    D = m2 * _sqrt(torch.sum(dx**2, 3) + 1e-6)
     D_max, _ = torch.max(D, -1, keepdim=True)
     D_adj = D + (1.0 - m2) * D_max
     if cfg.edge_cutoff is not None:
@@ -168,10 +180,10 @@ def rbf_expand(D: Tensor, num_rbf: int = 16) -> Tensor:
 def pair_distance_at_edges(A: Tensor, Bt: Tensor, E_idx: Tensor, formulation: str) -> Tensor:
     """sqrt(|A_i - B_j|^2 + 1e-6) at j = E_idx[i,k]   (:301-305)."""
     if formulation == "reference":
-        D = torch.sqrt(torch.sum((A[:, :, None, :] - Bt[:, None, :, :]) ** 2, -1) + 1e-6)
+        D = _sqrt(torch.sum((A[:, :, None, :] - Bt[:, None, :, :]) ** 2, -1) + 1e-6)
         return take_pairs(D, E_idx)
     Bj = take_neighbors(Bt, E_idx)
-    return torch.sqrt(torch.sum((A[:, :, None, :] - Bj) ** 2, -1) + 1e-6)
+    return _sqrt(torch.sum((A[:, :, None, :] - Bj) ** 2, -1) + 1e-6)
 
 
 def positional_codes(residue_idx: Tensor, chain_labels: Tensor, E_idx: Tensor, cfg: Config) -> Tensor:

@@ -67,18 +67,13 @@ def oracle_cfg(model_kwargs):
                   occupancy_cutoff=model_kwargs.get("occupancy_cutoff"))
 
 
-def untied_edge_mask(D_neighbors, D_full=None):
-    """True where a neighbour slot's rank is well defined: its distance differs from both adjacent
-    slots' and (when the full [B,L,L] adjusted-distance matrix is given) from every other column's,
-    which also catches a last slot that ties with the first excluded candidate."""
-    D = np.asarray(D_neighbors)
-    ne_prev = np.ones_like(D, bool)
-    ne_next = np.ones_like(D, bool)
-    ne_prev[..., 1:] = D[..., 1:] != D[..., :-1]
-    ne_next[..., :-1] = D[..., :-1] != D[..., 1:]
-    ok = ne_prev & ne_next
-    if D_full is not None:
-        F = np.asarray(D_full)
-        mult = (F[..., None, :] == D[..., :, None]).sum(-1)  # [B,L,K] multiplicity of each kept value
-        ok &= mult == 1
-    return ok
+def untied_edge_mask(D_neighbors, D_full, rel_gap=3e-7):
+    """True where a neighbour slot's rank is robust: no OTHER column of the full [B,L,L] adjusted
+    distance row lies within rel_gap (about 2 fp32 ulp) of the slot's distance.  Exact ties have an
+    implementation-defined order in torch.topk, and near-ties flip with the 1-ulp sqrt differences
+    between torch-CPU, CUDA and IEEE (see oracle._sqrt)."""
+    D = np.asarray(D_neighbors, np.float64)
+    F = np.asarray(D_full, np.float64)
+    tol = np.abs(D) * rel_gap
+    close = np.abs(F[..., None, :] - D[..., :, None]) <= tol[..., :, None]   # [B,L,K,L]
+    return close.sum(-1) <= 1

@@ -1,0 +1,191 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Bars: neighbour indices, neighbour distances, edge / causal masks bit-exact; log-probs within
+1e-4 relative (+1e-5 absolute) of the oracle in fp32."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden, oracle_cfg, untied_edge_mask
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+LP_RTOL, LP_ATOL = 1e-4, 1e-5
+
+
+def build_model(kw, device="cuda"):
+    import mpnn_amd
+    from mpnn_amd.synthetic import fill_parameters_
+
+    model = mpnn_amd.ProteinMPNN(augment_eps=0.0, dropout=0.0, **kw).eval()
+    fill_parameters_(model, seed=0)
+    return model.to(device)
+
+
+def run_hip(model, rec, keep=True):
+    from mpnn_amd import engine
+
+    d = "cuda"
+    noise = T(rec["backbone_noise"]).to(d) if "backbone_noise" in rec else None
+    order = None if "order_noise" in rec else T(rec["fix_order"]).to(d)
+    if "order_noise" in rec:  # reproduce the reference's internal draw on the host
+        cm = T(rec["chain_M"]) * T(rec["mask"])
+        order = torch.argsort((cm + 0.0001) * torch.abs(T(rec["order_noise"]))).to(d)
+    with torch.no_grad():
+        out = engine.forward(model, T(rec["X"]).to(d), T(rec["S"]).to(d), T(rec["mask"]).to(d),
+                             T(rec["chain_M"]).to(d), T(rec["residue_idx"]).to(d),
+                             T(rec["chain_encoding_all"]).to(d), fix_order=order, fix_backbone_noise=noise,
+                             return_intermediates=keep)
+    torch.cuda.synchronize()
+    return out
+
+
+def run_oracle(model, kw, rec):
+    from oracle import mpnn_oracle as orc
+
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = oracle_cfg(kw)
+    noise = T(rec["backbone_noise"]) if "backbone_noise" in rec else None
+    if "order_noise" in rec:
+        fo, on = None, T(rec["order_noise"])
+    else:
+        fo, on = T(rec["fix_order"]), None
+    with torch.no_grad():
+        return orc.forward(sd, cfg, T(rec["X"]), T(rec["S"]), T(rec["mask"]), T(rec["chain_M"]),
+                           T(rec["residue_idx"]), T(rec["chain_encoding_all"]), fix_order=fo,
+                           fix_backbone_noise=noise, order_noise=on, formulation="edge", keep=True)
+
+
+def same(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    bad = int((a != b).sum()) if a.shape == b.shape else -1
+    if bad:
+        where = np.argwhere(a != b)[:5].tolist() if bad > 0 else "shape"
+        raise AssertionError(f"{what}: {bad} of {a.size} entries differ, first at {where}")
+
+
+def assert_close(a, b, rtol, atol, what):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if a.size == 0:
+        return
+    err = np.abs(a - b) - (atol + rtol * np.abs(b))
+    assert err.max() <= 0, f"{what}: max |d| {np.abs(a - b).max():.3e} (worst excess {err.max():.3e})"
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_forward_vs_oracle(name):
+    rec, kw = load_golden(name)
+    model = build_model(kw)
+    out = run_hip(model, rec)
+    ref = run_oracle(model, kw, rec)
+    mask = rec["mask"].astype(bool)
+    # --- integer / mask work: bit exact against the oracle (same tie convention: by column index)
+    same(out["E_idx"].cpu().numpy(), ref["E_idx"].numpy(), "E_idx")
+    same(out["D_neighbors"].cpu().numpy(), ref["D_neighbors"].numpy(), "D_neighbors")
+    if ref["edge_mask"] is not None:
+        same(out["edge_mask"].cpu().numpy(), ref["edge_mask"].numpy(), "edge_mask")
+    same(out["mask_bw"].cpu().numpy(), ref["mask_bw"].numpy(), "mask_bw")
+    same(out["mask_fw"].cpu().numpy(), ref["mask_fw"].numpy(), "mask_fw")
+    if ref["occupancy"] is not None:
+        assert_close(out["occupancy"].cpu().numpy(), ref["occupancy"].numpy(), 1e-5, 1e-6, "occupancy")
+    # --- floating point stages (valid rows; padded rows of h_E feed nothing)
+    assert_close(out["h_E0"].cpu().numpy()[mask], ref["h_E0"].numpy()[mask], 1e-4, 2e-5, "h_E0")
+    for l in range(len(ref["h_V_enc"])):
+        assert_close(out["h_V_enc"][l].cpu().numpy(), ref["h_V_enc"][l].numpy(), 1e-4, 5e-5, f"enc{l} h_V")
+        assert_close(out["h_E_enc"][l].cpu().numpy()[mask], ref["h_E_enc"][l].numpy()[mask], 1e-4, 5e-5, f"enc{l} h_E")
+    for l in range(len(ref["h_V_dec"])):
+        assert_close(out["h_V_dec"][l].cpu().numpy(), ref["h_V_dec"][l].numpy(), 1e-4, 5e-5, f"dec{l} h_V")
+    assert_close(out["log_probs"].cpu().numpy(), ref["log_probs"].numpy(), LP_RTOL, LP_ATOL, "log_probs")
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_forward_vs_reference_golden(name):
+    """Directly against vectors the real reference produced (tests/golden/make_golden.py)."""
+    rec, kw = load_golden(name)
+    model = build_model(kw)
+    out = run_hip(model, rec)
+    from oracle import mpnn_oracle as orc
+    cfg = oracle_cfg(kw)
+    Xn = T(rec["X"]) + (T(rec["backbone_noise"]) if "backbone_noise" in rec else 0)
+    D_full = orc.adjusted_distances(Xn[:, :, 1], T(rec["mask"]), cfg).numpy()
+    untied = untied_edge_mask(rec["D_neighbors"], D_full)
+    E_idx = out["E_idx"].cpu().numpy()
+    same(E_idx[untied], rec["E_idx"][untied], "E_idx (robust slots) vs reference")
+    np.testing.assert_allclose(out["D_neighbors"].cpu().numpy(), rec["D_neighbors"], rtol=1.2e-7, atol=0)  # golden came from torch-CPU sqrt (1 ulp)
+    if "edge_mask" in rec:
+        same(out["edge_mask"].cpu().numpy(), rec["edge_mask"], "edge_mask vs reference")
+    mask = rec["mask"].astype(bool)
+    if "c_ties" in name:
+        # which padded columns fill tied slots is torch.topk-implementation defined and changes the
+        # decoder output: only proteins with >= K valid residues are comparable here
+        ok = mask & (rec["mask"].sum(-1, keepdims=True) >= rec["E_idx"].shape[-1])
+    else:
+        ok = mask
+    assert_close(out["log_probs"].cpu().numpy()[ok], rec["log_probs"][ok], LP_RTOL, LP_ATOL, "log_probs")
+    # padded rows: log_softmax(W_out.bias)
+    assert_close(out["log_probs"].cpu().numpy()[~mask], rec["log_probs"][~mask], 1e-6, 1e-6, "padded rows")
+
+
+def test_features_surface():
+    """model.features(...) keeps the reference's return tuple (reference :309, :360)."""
+    rec, kw = load_golden("g_all_B2_L128")
+    model = build_model(kw)
+    d = "cuda"
+    with torch.no_grad():
+        E, E_idx, occ, edge_mask = model.features(T(rec["X"]).to(d), T(rec["mask"]).to(d),
+                                                  T(rec["residue_idx"]).to(d), T(rec["chain_encoding_all"]).to(d))
+    ref = run_oracle(model, kw, rec)
+    mask = rec["mask"].astype(bool)
+    assert E_idx.dtype == torch.int64
+    same(E_idx.cpu().numpy(), ref["E_idx"].numpy(), "E_idx")
+    assert_close(E.cpu().numpy()[mask], ref["E"].numpy()[mask], 1e-4, 2e-5, "E")
+    same(edge_mask.cpu().numpy(), ref["edge_mask"].numpy(), "edge_mask")
+    assert occ.shape == (2, 128, 1)
+
+
+def test_enc_layer_surface():
+    """EncLayer.forward(h_V, h_E, E_idx, mask_V, mask_attend) in natural layouts (reference :73-95)."""
+    from oracle import mpnn_oracle as orc
+
+    rec, kw = load_golden("b_padded_B3_L96")
+    model = build_model(kw)
+    g = torch.Generator().manual_seed(0)
+    B, L, K = 3, 96, 48
+    h_V = torch.randn(B, L, 128, generator=g)
+    h_E = torch.randn(B, L, K, 128, generator=g)
+    E_idx = T(rec["E_idx"])
+    mask = T(rec["mask"])
+    m_att = mask.unsqueeze(-1) * torch.gather(mask, 1, E_idx.view(B, -1)).view(B, L, K)
+    layer = model.encoder_layers[1]
+    with torch.no_grad():
+        hv, he = layer(h_V.cuda(), h_E.cuda(), E_idx.cuda(), mask.cuda(), m_att.cuda())
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        rv, re = orc.enc_layer(sd, "encoder_layers.1", orc.Config(), h_V, h_E, E_idx, mask, m_att)
+    assert_close(hv.cpu().numpy(), rv.numpy(), 1e-4, 5e-5, "h_V")
+    assert_close(he.cpu().numpy(), re.numpy(), 1e-4, 5e-5, "h_E")
+
+
+def test_c2_shape_property_and_checksum():
+    """C2 shape (L=512, K=48): checksum record from the reference + permutation-equivariance over the
+    batch axis (proteins are independent), at B=8."""
+    import os
+    from conftest import GOLDEN
+    from mpnn_amd.synthetic import synthetic_batch
+
+    z = np.load(os.path.join(GOLDEN, "g_c2shape_B4_L512.npz"))
+    model = build_model(dict(k_neighbors=48))
+    b = synthetic_batch(B=4, L=512, seed=10, device="cuda")
+    with torch.no_grad():
+        lp = model(b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"],
+                   fix_order=b["fix_order"])
+        perm = torch.tensor([2, 0, 3, 1], device="cuda")
+        lp_p = model(b["X"][perm], b["S"][perm], b["mask"][perm], b["chain_M"][perm], b["residue_idx"][perm],
+                     b["chain_encoding_all"][perm], fix_order=b["fix_order"][perm])
+    assert torch.equal(lp[perm], lp_p), "batch permutation must commute bit-for-bit"
+    lp = lp.cpu()
+    assert_close(lp[:, :8].numpy(), z["lp_head"], LP_RTOL, LP_ATOL, "lp_head")
+    assert_close(lp.double().sum(-1).numpy(), z["lp_rowsum"], 1e-5, 2e-3, "row sums")
+    assert (lp.argmax(-1).numpy() == z["lp_argmax"]).mean() > 0.999
+    # log-probs normalise
+    assert_close(torch.logsumexp(lp.double(), -1).numpy(), np.zeros((4, 512)), 0, 1e-5, "normalisation")

@@ -1,0 +1,61 @@
+"""CPU-side checks: state_dict surface, C ABI exports, argument rejection (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def test_state_dict_matches_reference_layout():
+    import mpnn_amd
+    from mpnn_amd.params import param_shapes
+
+    for kw in (dict(), dict(use_virtual_center=True), dict(occupancy_cutoff=6.0, edge_cutoff=15.0)):
+        m = mpnn_amd.ProteinMPNN(**kw)
+        want = param_shapes(use_virtual_center=kw.get("use_virtual_center", False),
+                            occupancy_cutoff=kw.get("occupancy_cutoff"))
+        got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        assert got == dict(want)
+    assert sum(p.numel() for p in mpnn_amd.ProteinMPNN().parameters()) == 1660485
+
+
+def test_library_exports_every_declared_symbol():
+    from mpnn_amd import _lib
+
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "mpnn_hip.h")).read()
+    hdr_nocomment = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = list(dict.fromkeys(re.findall(r"\b(mpnn_\w+)\s*\(", hdr_nocomment)))
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), n
+        m = re.search(r"\b" + n + r"\s*\(([^;]*?)\);", hdr_nocomment, re.S)
+        args = [a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
+        if n in _lib.SIGNATURES:
+            assert len(args) == len(_lib.SIGNATURES[n]), n
+    assert lib.mpnn_version() >= 1
+
+
+def test_argument_rejection_without_gpu():
+    """Launchers validate before touching the device: bad arguments return -1 with a message."""
+    from mpnn_amd import _lib
+
+    lib = _lib.load()
+    rc = lib.mpnn_knn_topk(None, 1, 8, 4, 0.0, None, None, None, None, None)
+    assert rc == -1 and b"mpnn_knn_topk" in lib.mpnn_last_error()
+    rc = lib.mpnn_knn_topk(ctypes.c_void_p(16), 1, 8, 100, 0.0, None, ctypes.c_void_p(16), None, None, None)
+    assert rc == -1 and b"K" in lib.mpnn_last_error()
+
+
+def test_cpu_input_fails_loudly():
+    import mpnn_amd
+    from mpnn_amd.synthetic import synthetic_batch
+
+    m = mpnn_amd.ProteinMPNN(k_neighbors=8).eval()
+    b = synthetic_batch(1, 16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        with torch.no_grad():
+            m(b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
