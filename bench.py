@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Throughput bench of the ProteinMPNN hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one encoder+decoder forward (featurizer included, teacher-forced decoder, fixed random
+decoding order) over one batch of synthetic backbones of BASELINE.json configs[1]:
+B=32 x L=512, k=48, hidden 128, fp32, inputs resident in HBM.  Proteins are independent, so ranks
+take their own batch (weak scaling, no data-path collective).  Rank 0 prints ONE JSON line with the
+whole-job residues/s, the roofline of the dominant kernel (HIP-event timed on its launch stream) and
+the CPU baseline (the oracle's reference formulation on a bounded sample, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic FLOPs per residue as the reference writes the maths (SURVEY.md 8d, K=48, H=128)
+FLOP_FWD_PER_RES = 83.86e6
+FLOP_AS_WRITTEN = {  # per residue, per launch of the named entry point
+    "mpnn_enc_edge_update": 2 * 48 * (384 * 128 + 2 * 128 * 128),   # W11, W12, W13 (reference :93)
+    "mpnn_enc_message": 2 * 48 * (384 * 128 + 2 * 128 * 128),       # W1, W2, W3     (reference :78)
+    "mpnn_dec_message": 2 * 48 * (512 * 128 + 2 * 128 * 128),       # W1, W2, W3     (reference :124)
+    "mpnn_edge_features": 2 * 48 * (416 * 128 + 128 * 128 + 66 * 16),  # edge_embedding, W_e, positional
+}
+FLOP_EXECUTED = {  # what the kernel itself issues to the MFMA pipe (W1a/W1c and W3 live in the node kernel)
+    "mpnn_enc_edge_update": 2 * 48 * 3 * 128 * 128,
+    "mpnn_enc_message": 2 * 48 * 2 * 128 * 128,
+    "mpnn_dec_message": 2 * 48 * 2 * 128 * 128,
+    "mpnn_edge_features": 2 * 48 * (416 * 128 + 128 * 128),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+
+def cpu_baseline(B_cpu, L, K, iters):
+    """The oracle in the reference's formulation (same [B,L,L] temporaries and O(L^3) mask einsum),
+    timed on this host's cores."""
+    from mpnn_amd import ProteinMPNN
+    from mpnn_amd.synthetic import synthetic_batch
+    from oracle import mpnn_oracle as orc
+
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    model = ProteinMPNN(k_neighbors=K, augment_eps=0.0, dropout=0.0).eval()
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    cfg = orc.Config(k_neighbors=K)
+    b = synthetic_batch(B_cpu, L, seed=123)
+    args = (b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
+    times = []
+    with torch.no_grad():
+        orc.forward(sd, cfg, *args, fix_order=b["fix_order"], formulation="reference")  # warm-up
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            orc.forward(sd, cfg, *args, fix_order=b["fix_order"], formulation="reference")
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B_cpu * L / med, "unit": "residues/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (reference formulation, fp32, torch CPU) forward on B={B_cpu} x L={L}, k={K}: "
+                      f"median of {iters} runs after 1 warm-up, {med * 1e3:.0f} ms each"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--length", type=int, default=512)
+    ap.add_argument("--k", type=int, default=48)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            print(f"bench.py: --gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no ROCm device visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mpnn_amd import ProteinMPNN, _lib
+    from mpnn_amd.synthetic import synthetic_batch
+
+    B, L, K = a.batch, a.length, a.k
+    torch.manual_seed(1234)  # same random-init weights on every rank
+    model = ProteinMPNN(k_neighbors=K, augment_eps=0.0, dropout=0.0).eval().to(dev)
+    b = synthetic_batch(B, L, seed=1000 + rank, device=dev)
+    args = (b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
+
+    def step():
+        with torch.no_grad():
+            return model(*args, fix_order=b["fix_order"])
+
+    for _ in range(a.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out).all()
+
+    # ---- per-kernel device time (HIP events on the launch stream), separate from the timed region
+    prof = {}
+    _lib.set_profiler(prof)
+    psteps = max(3, min(10, a.steps))
+    for _ in range(psteps):
+        step()
+    torch.cuda.synchronize()
+    _lib.set_profiler(None)
+    per_kernel = {}
+    for name, evs in prof.items():
+        ms = [e0.elapsed_time(e1) for e0, e1 in evs]
+        per_kernel[name] = {"launches_per_step": len(ms) / psteps, "avg_ms": sum(ms) / len(ms),
+                            "ms_per_step": sum(ms) / psteps}
+    dominant = max(per_kernel, key=lambda n: per_kernel[n]["ms_per_step"])
+    dk = per_kernel[dominant]
+    roofline = None
+    if dominant in FLOP_AS_WRITTEN:
+        ach = FLOP_AS_WRITTEN[dominant] * B * L / (dk["avg_ms"] * 1e-3) / 1e12
+        exe = FLOP_EXECUTED[dominant] * B * L / (dk["avg_ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(dk["avg_ms"], 4), "executed_tflops": round(exe, 2),
+                    "executed_frac": round(exe / PEAK_F32_MFMA_TFLOPS, 4),
+                    "note": "achieved = as-written reference FLOPs of the op this launch replaces / HIP-event "
+                            "time; executed = FLOPs the kernel itself issues (W1a/W1c/W3 terms are hoisted to "
+                            "the node kernel)"}
+
+    if rank == 0:
+        total_res = B * L * world * a.steps
+        value = total_res / elapsed
+        line = {
+            "metric": "residues/sec (enc+dec fwd) at L=512,k=48",
+            "value": round(value, 1), "unit": "residues/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: synthetic backbones, batch {B} x L={L}, k={K}, hidden 128, "
+                                   "3 enc + 3 dec layers, fp32 forward + teacher-forced decoder",
+                       "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world} (proteins sharded, no collective)"},
+            "whole_forward_tflops_as_written": round(FLOP_FWD_PER_RES * value / 1e12, 2),
+            "roofline": roofline,
+            "kernels_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(per_kernel.items())},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(2, L, K, iters=3)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,9 +78,27 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+# optional per-entry-point device timing (bench.py): name -> list of (start_event, end_event),
+# recorded on the stream the kernels are launched on
+_profile = None
+
+
+def set_profiler(store):
+    """store: dict to fill with name -> [(start, end) torch.cuda.Event pairs], or None to switch off."""
+    global _profile
+    _profile = store
+
+
 def call(name: str, *args):
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if _profile is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        _profile.setdefault(name, []).append((e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.mpnn_last_error().decode(errors="replace")
         raise RuntimeError(f"{name} failed (code {rc}): {msg}")
