@@ -33,23 +33,23 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// erf with |abs err| < 2.5e-7 (Abramowitz-Stegun 7.1.26 evaluated in fp32)
-__device__ __forceinline__ float erf_as(float x) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+// exact-erf GELU (nn.GELU() default; reference model_utils.py:70,115,149):  0.5 x (1 + erf(x / sqrt 2)).
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7 + fp32 rounding), branch free:
+//   erf(|z|) = 1 - (a1 t + ... + a5 t^5) exp(-z^2),  t = 1 / (1 + p |z|)
+// ~15 VALU instructions, two of them transcendental (v_rcp_f32, v_exp_f32).
+__device__ __forceinline__ float gelu(float x) {
+  const float z = x * 0.70710678118654752440f;
+  const float az = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
   p = fmaf(p, t, 0.254829592f);
   p *= t;
-  const float e = __expf(-ax * ax);
-  const float y = fmaf(-p, e, 1.0f);
-  return copysignf(y, x);
-}
-
-// exact-erf GELU (nn.GELU() default; reference model_utils.py:70,115,149)
-__device__ __forceinline__ float gelu(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  const float zs = z * 1.20112240878644977f;          // sqrt(log2 e): exp(-z^2) = exp2(-(zs^2))
+  const float e = __builtin_amdgcn_exp2f(-(zs * zs));
+  const float r = (0.5f * x) * (p * e);               // 0.5 x erfc(|z|)
+  return x > 0.f ? x - r : r;                         // x Phi(x) without the 1 - erf cancellation for x < 0
 }
 
 __device__ __forceinline__ f32x4 gelu4(f32x4 v) {

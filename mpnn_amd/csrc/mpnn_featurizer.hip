@@ -313,8 +313,8 @@ k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, 
         const float d = sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float z = (d - mu[r]) / 1.25f;
-          x[c][r] = expf(-(z * z));
+          const float z = (d - mu[r]) * 0.96089792702915982f;  // (1 / 1.25) sqrt(log2 e)
+          x[c][r] = __builtin_amdgcn_exp2f(-(z * z));           // exp(-((d - mu) / 1.25)^2)
         }
       }
 #pragma unroll
