@@ -112,27 +112,27 @@ template <int KT>
 __device__ __forceinline__ void tile_layernorm(f32x4 (&V)[MPNN_NT][KT], const float* __restrict__ gamma,
                                                const float* __restrict__ beta, int lane) {
   const int g = lane >> 4;
-  f32x4 gm[MPNN_NT], bt[MPNN_NT];
-#pragma unroll
-  for (int t = 0; t < MPNN_NT; ++t) {
-    gm[t] = *reinterpret_cast<const f32x4*>(gamma + 16 * t + 4 * g);
-    bt[t] = *reinterpret_cast<const f32x4*>(beta + 16 * t + 4 * g);
-  }
+  float mean[KT], rstd[KT];
 #pragma unroll
   for (int c = 0; c < KT; ++c) {
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) s += (V[t][c].x + V[t][c].y) + (V[t][c].z + V[t][c].w);
-    const float mean = quarter_sum(s) * (1.0f / MPNN_H);
+    mean[c] = quarter_sum(s) * (1.0f / MPNN_H);
     float q = 0.f;
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
-      const f32x4 d = V[t][c] - mean;
+      const f32x4 d = V[t][c] - mean[c];
       q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
     }
-    const float rstd = rsqrtf(quarter_sum(q) * (1.0f / MPNN_H) + MPNN_LN_EPS);
+    rstd[c] = rsqrtf(quarter_sum(q) * (1.0f / MPNN_H) + MPNN_LN_EPS);
+  }
 #pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t) V[t][c] = (V[t][c] - mean) * rstd * gm[t] + bt[t];
+  for (int t = 0; t < MPNN_NT; ++t) {
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 16 * t + 4 * g);
+    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 16 * t + 4 * g);
+#pragma unroll
+    for (int c = 0; c < KT; ++c) V[t][c] = (V[t][c] - mean[c]) * rstd[c] * gm + bt;
   }
 }
 

@@ -13,8 +13,13 @@
 // persistent (grid = #CUs) and stride over residues.
 #include "mpnn_common.h"
 
-#ifndef MPNN_EDGE_WAVES
-#define MPNN_EDGE_WAVES 4
+// waves per persistent workgroup (LDS holds 128 KiB of weights, so one workgroup per CU):
+// 8 waves = two per SIMD (<= 256 registers each), 4 waves = one per SIMD (512 registers)
+#ifndef MPNN_MSG_WAVES
+#define MPNN_MSG_WAVES 8
+#endif
+#ifndef MPNN_UPD_WAVES
+#define MPNN_UPD_WAVES 8
 #endif
 
 __device__ __forceinline__ void lds_fill(f32x4* dst, const f32x4* __restrict__ src, int n4) {
@@ -26,7 +31,7 @@ __device__ __forceinline__ void lds_fill(f32x4* dst, const f32x4* __restrict__ s
 //   m_ik = mask_i mask_j (edge_mask_ik)      (reference :467-470, :75-81)
 // ---------------------------------------------------------------------------
 template <int KT>
-__global__ void __launch_bounds__(MPNN_EDGE_WAVES * 64)
+__global__ void __launch_bounds__(MPNN_MSG_WAVES * 64)
 k_enc_message(const f32x4* __restrict__ hE, const float* __restrict__ PQ, int ldpq, int offP, int offQ,
               const int* __restrict__ E_idx, const float* __restrict__ mask, const float* __restrict__ edge_mask,
               const f32x4* __restrict__ W1b, const f32x4* __restrict__ W2, const float* __restrict__ b2, int N,
@@ -41,7 +46,7 @@ k_enc_message(const f32x4* __restrict__ hE, const float* __restrict__ PQ, int ld
   const int g = lane >> 4, col = lane & 15;
   constexpr int Kp = KT * 16;
 
-  for (int node = blockIdx.x * MPNN_EDGE_WAVES + wave; node < N; node += gridDim.x * MPNN_EDGE_WAVES) {
+  for (int node = blockIdx.x * MPNN_MSG_WAVES + wave; node < N; node += gridDim.x * MPNN_MSG_WAVES) {
     const int b = node / L;
     const float mi = mask[node];
     int jn[KT];
@@ -119,7 +124,7 @@ k_enc_message(const f32x4* __restrict__ hE, const float* __restrict__ PQ, int ld
 //   (reference :90-95; unmasked).  W11b, W12 in LDS, W13 streamed from L2.  In place on hE.
 // ---------------------------------------------------------------------------
 template <int KT>
-__global__ void __launch_bounds__(MPNN_EDGE_WAVES * 64)
+__global__ void __launch_bounds__(MPNN_UPD_WAVES * 64)
 k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ PQ, int ldpq, int offP, int offQ,
                   const int* __restrict__ E_idx, const f32x4* __restrict__ W11b, const f32x4* __restrict__ W12,
                   const float* __restrict__ b12, const f32x4* __restrict__ W13, const float* __restrict__ b13,
@@ -134,7 +139,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ PQ, int ldpq
   const int g = lane >> 4, col = lane & 15;
   constexpr int Kp = KT * 16;
 
-  for (int node = blockIdx.x * MPNN_EDGE_WAVES + wave; node < N; node += gridDim.x * MPNN_EDGE_WAVES) {
+  for (int node = blockIdx.x * MPNN_UPD_WAVES + wave; node < N; node += gridDim.x * MPNN_UPD_WAVES) {
     const int b = node / L;
     int jn[KT];
 #pragma unroll
@@ -202,7 +207,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ PQ, int ldpq
 //   gsum[i] = sum_{k<K} gelu(W2 gelu(acc0 + W1b (..)) + b2)          (no attention mask: :525)
 // ---------------------------------------------------------------------------
 template <int KT>
-__global__ void __launch_bounds__(MPNN_EDGE_WAVES * 64)
+__global__ void __launch_bounds__(MPNN_MSG_WAVES * 64)
 k_dec_message(const f32x4* __restrict__ hE, const float* __restrict__ PQ, int ldpq, int offPa, int offPV,
               const float* __restrict__ PVenc, int ldenc, int offEnc, const float* __restrict__ TS, int ldts,
               int offTS, const long long* __restrict__ S, const int* __restrict__ rank,
@@ -219,7 +224,7 @@ k_dec_message(const f32x4* __restrict__ hE, const float* __restrict__ PQ, int ld
   const int g = lane >> 4, col = lane & 15;
   constexpr int Kp = KT * 16;
 
-  for (int node = blockIdx.x * MPNN_EDGE_WAVES + wave; node < N; node += gridDim.x * MPNN_EDGE_WAVES) {
+  for (int node = blockIdx.x * MPNN_MSG_WAVES + wave; node < N; node += gridDim.x * MPNN_MSG_WAVES) {
     const int b = node / L;
     const float mi = mask[node];
     const int ri = rank[node];
@@ -450,13 +455,13 @@ k_logits(const float* __restrict__ hV, const f32x4* __restrict__ Wp, const float
 // ===========================================================================
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-static int edge_grid(int N) {
+static int edge_grid(int N, int waves) {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
-  const int want = ceil_div(N, MPNN_EDGE_WAVES);
+  const int want = ceil_div(N, waves);
   return want < cus ? want : cus;
 }
 
@@ -477,7 +482,7 @@ extern "C" int mpnn_enc_message(const float* hE_frag, const float* PQ, int ldpq,
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && ldpq >= 128 && (ldpq % 4) == 0 && (offP % 4) == 0 && (offQ % 4) == 0,
                  "mpnn_enc_message: bad sizes");
   const int N = B * L, KT = (K + 15) / 16;
-  dim3 grid(edge_grid(N)), block(MPNN_EDGE_WAVES * 64);
+  dim3 grid(edge_grid(N, MPNN_MSG_WAVES)), block(MPNN_MSG_WAVES * 64);
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_enc_message<kKT>), grid, block, 0, (hipStream_t)stream, (const f32x4*)hE_frag,
                                      PQ, ldpq, offP, offQ, E_idx32, mask, edge_mask, (const f32x4*)W1b_packed,
                                      (const f32x4*)W2_packed, b2, N, L, K, gsum, cnt));
@@ -493,7 +498,7 @@ extern "C" int mpnn_enc_edge_update(float* hE_frag, const float* PQ, int ldpq, i
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && ldpq >= 128 && (ldpq % 4) == 0 && (offP % 4) == 0 && (offQ % 4) == 0,
                  "mpnn_enc_edge_update: bad sizes");
   const int N = B * L, KT = (K + 15) / 16;
-  dim3 grid(edge_grid(N)), block(MPNN_EDGE_WAVES * 64);
+  dim3 grid(edge_grid(N, MPNN_UPD_WAVES)), block(MPNN_UPD_WAVES * 64);
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_enc_edge_update<kKT>), grid, block, 0, (hipStream_t)stream, (f32x4*)hE_frag, PQ,
                                      ldpq, offP, offQ, E_idx32, (const f32x4*)W11b_packed, (const f32x4*)W12_packed,
                                      b12, (const f32x4*)W13_packed, b13, ln_w, ln_b, N, L));
@@ -510,7 +515,7 @@ extern "C" int mpnn_dec_message(const float* hE_frag, const float* PQ, int ldpq,
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64, "mpnn_dec_message: bad sizes");
   MPNN_CHECK_ARG(((ldpq | offPa | offPV | ldenc | offEnc | ldts | offTS) % 4) == 0, "mpnn_dec_message: strides/offsets must be multiples of 4 floats");
   const int N = B * L, KT = (K + 15) / 16;
-  dim3 grid(edge_grid(N)), block(MPNN_EDGE_WAVES * 64);
+  dim3 grid(edge_grid(N, MPNN_MSG_WAVES)), block(MPNN_MSG_WAVES * 64);
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_dec_message<kKT>), grid, block, 0, (hipStream_t)stream, (const f32x4*)hE_frag,
                                      PQ, ldpq, offPa, offPV, PVenc, ldenc, offEnc, TS, ldts, offTS, (const long long*)S,
                                      rank, E_idx32, mask, edge_mask, (const f32x4*)W1b_packed, (const f32x4*)W2_packed,
