@@ -88,23 +88,27 @@ int mpnn_enc_edge_update(float* hE_frag, const float* PQ, int ldpq, int offP, in
                          int L, int K, void* stream);
 
 /* Decoder input assembly + DecLayer message (:478-483, :507-525, :121-127), nothing materialised:
- *   acc0 = Pa_i + bw_ik (TS[S_j] + PV_j) + fw_ik PVenc_j,   gsum[i] = sum_{k<K} gelu(W2 gelu(acc0 + W1b (bw+fw) e_ik) + b2)
- *   Pa = W1a h + b1, PV = W1d h (columns of PQ); PVenc = W1d h_enc; TS = W1c W_s^T (per-letter table, row stride ldts). */
-int mpnn_dec_message(const float* hE_frag, const float* PQ, int ldpq, int offPa, int offPV, const float* PVenc,
-                     int ldenc, int offEnc, const float* TS, int ldts, int offTS, const int64_t* S,
-                     const int32_t* rank, const int32_t* E_idx32, const float* mask, const float* edge_mask,
-                     const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K, float* gsum,
-                     void* stream);
+ *   s_ik = mask_i edge_mask_ik;  Row_ik = (rank_j < rank_i) ? A_j : PVenc_j   (ONE gathered row per edge)
+ *   gsum[i] = sum_{k<K} gelu(W2 gelu(Pa_i + s_ik (Row_ik + W1b e_ik)) + b2)
+ *   Pa = W1a h + b1 and A = W1d h + W1c W_s[S] are columns [offPa,+128) / [offA,+128) of PQ (mpnn_node_update
+ *   with its table-add); PVenc = W1d h_enc is columns [offEnc,+128) of a buffer with row stride ldenc. */
+int mpnn_dec_message(const float* hE_frag, const float* PQ, int ldpq, int offPa, int offA, const float* PVenc,
+                     int ldenc, int offEnc, const int32_t* rank, const int32_t* E_idx32, const float* mask,
+                     const float* edge_mask, const float* W1b_packed, const float* W2_packed, const float* b2, int B,
+                     int L, int K, float* gsum, void* stream);
 
 /* Node update shared by EncLayer / DecLayer (:81-88, :127-137, FFN :151-155) followed by the next kernels'
  * node projections:  dh = (W3 gsum + cnt b3) / scale;  x = LN1(h + dh);  h' = mask LN2(x + FFN(x));
- *   PQ[n, 128 p : 128 (p+1)] = Wproj_p h' + bproj_p,  p < nproj.
+ *   PQ[n, 128 p : 128 (p+1)] = Wproj_p h' + bproj_p,  p < nproj;
+ *   if add_table: PQ[n, block add_block] += add_table[add_idx[n]][off_table : off_table+128]  (row stride ld_table;
+ *   the decoder's per-letter sequence term W1c W_s[S_n], :478-479).
  * cnt == NULL uses cnt_const for every node (decoder: K).  do_update = 0 only projects hV_in. */
 int mpnn_node_update(const float* hV_in, const float* gsum, const float* cnt, float cnt_const, const float* mask,
                      const float* W3_packed, const float* b3, const float* ln1_w, const float* ln1_b,
                      const float* Win_packed, const float* b_in, const float* Wout_packed, const float* b_out,
                      const float* ln2_w, const float* ln2_b, float scale, int do_update, const float* Wproj_packed,
-                     const float* bproj, int nproj, int n_nodes, float* hV_out, float* PQ, void* stream);
+                     const float* bproj, int nproj, const float* add_table, int ld_table, int off_table,
+                     const int64_t* add_idx, int add_block, int n_nodes, float* hV_out, float* PQ, void* stream);
 
 /* occupancy_mlp (:414-421, :461-462): hV = LN(W2 gelu(w0 occ + b0) + b2). */
 int mpnn_occupancy_mlp(const float* occ, const float* w0, const float* b0, const float* W2_packed, const float* b2,

@@ -32,10 +32,9 @@ SIGNATURES = {
     "mpnn_order_masks": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "mpnn_enc_message": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "mpnn_enc_edge_update": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "mpnn_dec_message": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I,
-                         _P, _P],
-    "mpnn_node_update": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _I, _I, _P,
-                         _P, _P],
+    "mpnn_dec_message": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
+    "mpnn_node_update": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _I,
+                         _P, _I, _I, _P, _I, _I, _P, _P, _P],
     "mpnn_occupancy_mlp": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "mpnn_logits_log_softmax": [_P, _P, _P, _I, _I, _P, _P],
 }

@@ -1,0 +1,428 @@
+// Per-edge message-passing kernels for gfx950
+// (reference: src/mpnn/models/model_utils.py EncLayer :48-95, DecLayer :98-138,
+//  decoder input assembly :478-525).
+//
+// Algebra (exact in real arithmetic, fp32 re-association only):
+//   W1 [h_i | e_ik | h_j] = (W1a h_i + b1) + W1b e_ik + W1c h_j
+//        -> h_i / h_j terms are per-NODE projections (node kernel); each edge gathers ONE 512-B row
+//           of them as the accumulator's initial value, only W1b is per edge.
+//   sum_k m_k (W3 g_k + b3) = W3 (sum_k m_k g_k) + (sum_k m_k) b3
+//        -> W3 moves to the node kernel; the edge kernel emits gsum and cnt.
+//   decoder: input_ik = [h_i | s e_ik | bw h_S[j] | bw h_V[j] + fw h_Venc[j]], bw = s [rank_j < rank_i],
+//            fw = s - bw, s = mask_i edge_mask_ik  =>  W1 input = Pa_i + s (Row_ik + W1b e_ik),
+//            Row_ik = (rank_j < rank_i) ? (W1c h_S[j] + W1d h_V[j]) : W1d h_Venc[j]      (one gathered row)
+//
+// Structure: one wavefront owns one residue (KT column tiles of 16 neighbours, fragment layout of
+// mpnn_common.h), workgroups are persistent (grid = #CUs) and stride over residues with the two
+// per-edge 128x128 weights resident in LDS (128 KiB).  Loads are software-pipelined by hand:
+//   * hE k-tiles are double-buffered one tile ahead of their MFMAs,
+//   * the NEXT residue's neighbour rows are loaded into each accumulator tile right after the
+//     current residue's last read of it, its index/mask scalars one phase earlier,
+//   * the edge update streams its third weight matrix from L2 three fragments ahead.
+// Two waves per SIMD (8-wave workgroups) let one wave's GELU / reductions run under the other's MFMAs.
+#include "mpnn_common.h"
+
+#ifndef MPNN_MSG_WAVES
+#define MPNN_MSG_WAVES 8
+#endif
+#ifndef MPNN_UPD_WAVES
+#define MPNN_UPD_WAVES 8
+#endif
+
+// make a (uniform) pointer opaque once per loop iteration: keeps LICM from hoisting hundreds of
+// loop-invariant weight / bias loads out of the persistent loop and pinning them in registers
+#define LAUNDER(p) asm volatile("" : "+s"(p))
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ void lds_fill(f32x4* dst, const f32x4* __restrict__ src, int n4) {
+  for (int i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+}
+
+__device__ __forceinline__ f32x4 row_tile(const float* row, int t) {
+  return *reinterpret_cast<const f32x4*>(row + 16 * t);
+}
+
+// acc[to][c] += W[to][ti] * x[c]  for to in [TO0, TO1) at one k-tile ti (weights in LDS)
+template <int KT, int TO0, int TO1>
+__device__ __forceinline__ void mfma_ktile(const f32x4* Ws, int ti, int lane, const f32x4 (&x)[KT],
+                                           f32x4 (&acc)[TO1 - TO0][KT]) {
+#pragma unroll
+  for (int to = TO0; to < TO1; ++to) {
+    const f32x4 a = Ws[(to * MPNN_NT + ti) * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) acc[to - TO0][c] = mfma4(a[r], x[c][r], acc[to - TO0][c]);
+  }
+}
+
+// layer 1 of every edge MLP: acc += W1b * hE[node], hE k-tiles double-buffered from HBM
+template <int KT>
+__device__ __forceinline__ void layer1_stream(const f32x4* Ws, const f32x4* __restrict__ x, int lane,
+                                              f32x4 (&acc)[MPNN_NT][KT]) {
+  f32x4 xb[2][KT];
+#pragma unroll
+  for (int c = 0; c < KT; ++c) xb[0][c] = x[c * 64];
+#pragma unroll
+  for (int ti = 0; ti < MPNN_NT; ++ti) {
+    if (ti + 1 < MPNN_NT) {
+#pragma unroll
+      for (int c = 0; c < KT; ++c) xb[(ti + 1) & 1][c] = x[((ti + 1) * KT + c) * 64];
+    }
+    mfma_ktile<KT, 0, MPNN_NT>(Ws, ti, lane, xb[ti & 1], acc);
+    FENCE();
+  }
+}
+
+// masked neighbour sum of gelu(y) over the residue's edges -> gsum tile rows [T0, T0+4)
+template <int KT>
+__device__ __forceinline__ void reduce_store(f32x4 (&y)[4][KT], const float (&w)[KT], float* __restrict__ out,
+                                             int T0, int lane) {
+  const int g = lane >> 4, col = lane & 15;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KT; ++c) s += gelu4(y[t][c]) * w[c];
+    s.x = column_sum(s.x); s.y = column_sum(s.y); s.z = column_sum(s.z); s.w = column_sum(s.w);
+    if (col == 0) *reinterpret_cast<f32x4*>(out + 16 * (T0 + t) + 4 * g) = s;
+    FENCE();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// message kernel, encoder (DEC = false) and decoder (DEC = true):
+//   h1   = gelu(P_i + s_ik (Row_ik + W1b e_ik))
+//   gsum = sum_k w_ik gelu(W2 h1 + b2)
+//   enc: Row = Q_j, s = 1, w = mask_i mask_j edge_mask_ik, cnt = sum_k w       (:75-81, :467-470)
+//   dec: Row by decoding rank (see header), s = mask_i edge_mask_ik, w = [k < K] (:478-525, :121-127)
+// ---------------------------------------------------------------------------
+template <int KT, bool DEC>
+__global__ void __launch_bounds__(MPNN_MSG_WAVES * 64)
+k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp, int offP,
+          const float* __restrict__ Abuf, int lda, int offA, const float* __restrict__ Bbuf, int ldb, int offB,
+          const int* __restrict__ rank, const int* __restrict__ E_idx, const float* __restrict__ mask,
+          const float* __restrict__ edge_mask, const f32x4* __restrict__ W1b, const f32x4* __restrict__ W2,
+          const float* __restrict__ b2, int N, int L, int K, float* __restrict__ gsum, float* __restrict__ cnt) {
+  __shared__ f32x4 lds[2 * 64 * 64];
+  lds_fill(lds, W1b, 4096);
+  lds_fill(lds + 4096, W2, 4096);
+  __syncthreads();
+  const f32x4* W1s = lds;
+  const f32x4* W2s = lds + 4096;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  constexpr int Kp = KT * 16;
+  const int stride = gridDim.x * MPNN_MSG_WAVES;
+  int node = blockIdx.x * MPNN_MSG_WAVES + wave;
+  if (node >= N) return;
+
+  // per-edge scalars of a residue: gathered row, scale s (dec), reduction weight w
+  auto setup = [&](int nd, const float* (&row)[KT], float (&s)[KT], float (&w)[KT]) {
+    const int b = nd / L;
+    const float mi = mask[nd];
+    int ri = 0;
+    if (DEC) ri = rank[nd];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      const int e = 16 * c + col;
+      const int jn = b * L + E_idx[(size_t)nd * Kp + e];
+      float em = 1.0f;
+      if (edge_mask && e < K) em = edge_mask[(size_t)nd * K + e];
+      if (DEC) {
+        const bool before = ri > rank[jn];
+        row[c] = before ? (Abuf + (size_t)jn * lda + offA + 4 * g) : (Bbuf + (size_t)jn * ldb + offB + 4 * g);
+        s[c] = mi * em;
+        w[c] = e < K ? 1.0f : 0.0f;
+      } else {
+        row[c] = Abuf + (size_t)jn * lda + offA + 4 * g;
+        s[c] = 1.0f;
+        w[c] = e < K ? mi * mask[jn] * em : 0.0f;
+      }
+    }
+  };
+
+  const float* row[KT];
+  float s[KT], w[KT];
+  setup(node, row, s, w);
+  f32x4 h1[MPNN_NT][KT];
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+    for (int c = 0; c < KT; ++c) h1[t][c] = row_tile(row[c], t);
+
+  for (; node < N; node += stride) {
+    const int nxt = (node + stride < N) ? node + stride : N - 1;  // tail: harmless re-load of a valid residue
+    LAUNDER(b2);
+    // P_i: needed only after layer 1
+    f32x4 p[MPNN_NT];
+    {
+      const float* Pi = Pbuf + (size_t)node * ldp + offP + 4 * g;
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t) p[t] = row_tile(Pi, t);
+    }
+    layer1_stream<KT>(W1s, hE + (size_t)node * (MPNN_NT * KT * 64) + lane, lane, h1);
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+#pragma unroll
+      for (int c = 0; c < KT; ++c) h1[t][c] = gelu4(DEC ? (h1[t][c] * s[c] + p[t]) : (h1[t][c] + p[t]));
+      FENCE();
+    }
+    // next residue's scalars (their loads fly under layer 2, first half)
+    const float* rown[KT];
+    float sn[KT], wn[KT];
+    setup(nxt, rown, sn, wn);
+    float* gout = gsum + (size_t)node * MPNN_H;
+    // ---- layer 2, output rows 0..63
+    {
+      f32x4 y[4][KT];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + 16 * t + 4 * g);
+#pragma unroll
+        for (int c = 0; c < KT; ++c) y[t][c] = bb;
+      }
+#pragma unroll
+      for (int ti = 0; ti < MPNN_NT; ++ti) {
+        mfma_ktile<KT, 0, 4>(W2s, ti, lane, h1[ti], y);
+        FENCE();
+      }
+      reduce_store<KT>(y, w, gout, 0, lane);
+    }
+    // ---- layer 2, output rows 64..127; each h1 tile is refilled with the next residue's row once consumed
+    {
+      f32x4 y[4][KT];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + 16 * (4 + t) + 4 * g);
+#pragma unroll
+        for (int c = 0; c < KT; ++c) y[t][c] = bb;
+      }
+#pragma unroll
+      for (int ti = 0; ti < MPNN_NT; ++ti) {
+        mfma_ktile<KT, 4, 8>(W2s, ti, lane, h1[ti], y);
+        FENCE();
+#pragma unroll
+        for (int c = 0; c < KT; ++c) h1[ti][c] = row_tile(rown[c], ti);
+      }
+      reduce_store<KT>(y, w, gout, 4, lane);
+    }
+    if (!DEC) {
+      float csum = 0.f;
+#pragma unroll
+      for (int c = 0; c < KT; ++c) csum += w[c];
+      csum = column_sum(csum);
+      if (lane == 0) cnt[node] = csum;
+    }
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      s[c] = sn[c];
+      w[c] = wn[c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// encoder edge update, in place on hE (reference :90-95; unmasked):
+//   e_ik <- LN3(e_ik + W13 gelu(W12 gelu(P'_i + Q'_j + W11b e_ik) + b12) + b13)
+// W11b, W12 in LDS; W13 streams from L2 (A fragments three ahead of their MFMAs).
+// ---------------------------------------------------------------------------
+template <int KT>
+__global__ void __launch_bounds__(MPNN_UPD_WAVES * 64)
+k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ PQ, int ldpq, int offP, int offQ,
+                  const int* __restrict__ E_idx, const f32x4* __restrict__ W11b, const f32x4* __restrict__ W12,
+                  const float* __restrict__ b12, const f32x4* __restrict__ W13, const float* __restrict__ b13,
+                  const float* __restrict__ ln_w, const float* __restrict__ ln_b, int N, int L) {
+  __shared__ f32x4 lds[2 * 64 * 64];
+  lds_fill(lds, W11b, 4096);
+  lds_fill(lds + 4096, W12, 4096);
+  __syncthreads();
+  const f32x4* W1s = lds;
+  const f32x4* W2s = lds + 4096;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  constexpr int Kp = KT * 16;
+  const int stride = gridDim.x * MPNN_UPD_WAVES;
+  int node = blockIdx.x * MPNN_UPD_WAVES + wave;
+  if (node >= N) return;
+
+  auto setup = [&](int nd, const float* (&row)[KT]) {
+    const int b = nd / L;
+#pragma unroll
+    for (int c = 0; c < KT; ++c)
+      row[c] = PQ + (size_t)(b * L + E_idx[(size_t)nd * Kp + 16 * c + col]) * ldpq + offQ + 4 * g;
+  };
+
+  const float* row[KT];
+  setup(node, row);
+  f32x4 h2[MPNN_NT][KT];  // carries the next residue's gathered Q' rows across iterations
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+    for (int c = 0; c < KT; ++c) h2[t][c] = row_tile(row[c], t);
+
+  for (; node < N; node += stride) {
+    const int nxt = (node + stride < N) ? node + stride : N - 1;
+    LAUNDER(b12);
+    LAUNDER(b13);
+    LAUNDER(ln_w);
+    LAUNDER(ln_b);
+    const f32x4* W3u = W13;
+    LAUNDER(W3u);
+    const f32x4* W3g = W3u + lane;
+    f32x4* x = hE + (size_t)node * (MPNN_NT * KT * 64) + lane;
+    f32x4 p[MPNN_NT];
+    {
+      const float* Pi = PQ + (size_t)node * ldpq + offP + 4 * g;
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t) p[t] = row_tile(Pi, t);
+    }
+    f32x4 h1[MPNN_NT][KT];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) h1[t][c] = h2[t][c];
+    layer1_stream<KT>(W1s, x, lane, h1);
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+#pragma unroll
+      for (int c = 0; c < KT; ++c) h1[t][c] = gelu4(h1[t][c] + p[t]);
+      FENCE();
+    }
+    const float* rown[KT];
+    setup(nxt, rown);
+    // ---- layer 2; each consumed h1 tile is refilled with the residual e (layer 3's initial accumulator)
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(b12 + 16 * t + 4 * g);
+#pragma unroll
+      for (int c = 0; c < KT; ++c) h2[t][c] = bb;
+    }
+#pragma unroll
+    for (int ti = 0; ti < MPNN_NT; ++ti) {
+      mfma_ktile<KT, 0, MPNN_NT>(W2s, ti, lane, h1[ti], h2);
+      FENCE();
+#pragma unroll
+      for (int c = 0; c < KT; ++c) h1[ti][c] = x[(ti * KT + c) * 64];
+    }
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+#pragma unroll
+      for (int c = 0; c < KT; ++c) h2[t][c] = gelu4(h2[t][c]);
+      FENCE();
+    }
+    // ---- layer 3 on top of the residual; W13 fragments from L2, three ahead
+    {
+      constexpr int D = 3;
+      f32x4 a[D + 1];
+#pragma unroll
+      for (int q = 0; q < D; ++q) a[q] = W3g[((q & 7) * MPNN_NT + (q >> 3)) * 64];  // q = ti*8 + to
+#pragma unroll
+      for (int ti = 0; ti < MPNN_NT; ++ti) {
+#pragma unroll
+        for (int to = 0; to < MPNN_NT; ++to) {
+          const int q = ti * MPNN_NT + to;
+          if (q + D < 64) a[(q + D) % (D + 1)] = W3g[(((q + D) & 7) * MPNN_NT + ((q + D) >> 3)) * 64];
+          const f32x4 aa = a[q % (D + 1)];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < KT; ++c) h1[to][c] = mfma4(aa[r], h2[ti][c][r], h1[to][c]);
+        }
+        FENCE();
+        // h2[ti] is dead: start gathering the next residue's Q' rows into it
+#pragma unroll
+        for (int c = 0; c < KT; ++c) h2[ti][c] = row_tile(rown[c], ti);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(b13 + 16 * t + 4 * g);
+#pragma unroll
+      for (int c = 0; c < KT; ++c) h1[t][c] += bb;
+    }
+    tile_layernorm<KT>(h1, ln_w, ln_b, lane);
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) x[(t * KT + c) * 64] = h1[t][c];
+  }
+}
+
+// ===========================================================================
+// C ABI launchers
+// ===========================================================================
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+static int edge_grid(int N, int waves) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  const int want = ceil_div(N, waves);
+  return want < cus ? want : cus;
+}
+
+#define KT_DISPATCH(KT, CALL)   \
+  switch (KT) {                 \
+    case 1: { constexpr int kKT = 1; CALL; } break; \
+    case 2: { constexpr int kKT = 2; CALL; } break; \
+    case 3: { constexpr int kKT = 3; CALL; } break; \
+    default: { constexpr int kKT = 4; CALL; } break; \
+  }
+
+static bool mult4(int a, int b = 0, int c = 0, int d = 0, int e = 0, int f = 0) {
+  return ((a | b | c | d | e | f) & 3) == 0;
+}
+
+extern "C" int mpnn_enc_message(const float* hE_frag, const float* PQ, int ldpq, int offP, int offQ,
+                                const int32_t* E_idx32, const float* mask, const float* edge_mask,
+                                const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K,
+                                float* gsum, float* cnt, void* stream) {
+  MPNN_CHECK_ARG(hE_frag && PQ && E_idx32 && mask && W1b_packed && W2_packed && b2 && gsum && cnt,
+                 "mpnn_enc_message: null pointer");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && ldpq >= 128 && mult4(ldpq, offP, offQ),
+                 "mpnn_enc_message: bad sizes (strides/offsets must be multiples of 4 floats)");
+  const int N = B * L, KT = (K + 15) / 16;
+  dim3 grid(edge_grid(N, MPNN_MSG_WAVES)), block(MPNN_MSG_WAVES * 64);
+  KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, false>), grid, block, 0, (hipStream_t)stream,
+                                     (const f32x4*)hE_frag, PQ, ldpq, offP, PQ, ldpq, offQ, (const float*)nullptr, 0, 0,
+                                     (const int*)nullptr, E_idx32, mask, edge_mask, (const f32x4*)W1b_packed,
+                                     (const f32x4*)W2_packed, b2, N, L, K, gsum, cnt));
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_enc_edge_update(float* hE_frag, const float* PQ, int ldpq, int offP, int offQ,
+                                    const int32_t* E_idx32, const float* W11b_packed, const float* W12_packed,
+                                    const float* b12, const float* W13_packed, const float* b13, const float* ln_w,
+                                    const float* ln_b, int B, int L, int K, void* stream) {
+  MPNN_CHECK_ARG(hE_frag && PQ && E_idx32 && W11b_packed && W12_packed && b12 && W13_packed && b13 && ln_w && ln_b,
+                 "mpnn_enc_edge_update: null pointer");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && ldpq >= 128 && mult4(ldpq, offP, offQ),
+                 "mpnn_enc_edge_update: bad sizes (strides/offsets must be multiples of 4 floats)");
+  const int N = B * L, KT = (K + 15) / 16;
+  dim3 grid(edge_grid(N, MPNN_UPD_WAVES)), block(MPNN_UPD_WAVES * 64);
+  KT_DISPATCH(KT, hipLaunchKernelGGL((k_enc_edge_update<kKT>), grid, block, 0, (hipStream_t)stream, (f32x4*)hE_frag, PQ,
+                                     ldpq, offP, offQ, E_idx32, (const f32x4*)W11b_packed, (const f32x4*)W12_packed,
+                                     b12, (const f32x4*)W13_packed, b13, ln_w, ln_b, N, L));
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_dec_message(const float* hE_frag, const float* PQ, int ldpq, int offPa, int offA,
+                                const float* PVenc, int ldenc, int offEnc, const int32_t* rank,
+                                const int32_t* E_idx32, const float* mask, const float* edge_mask,
+                                const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K,
+                                float* gsum, void* stream) {
+  MPNN_CHECK_ARG(hE_frag && PQ && PVenc && rank && E_idx32 && mask && W1b_packed && W2_packed && b2 && gsum,
+                 "mpnn_dec_message: null pointer");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && mult4(ldpq, offPa, offA, ldenc, offEnc),
+                 "mpnn_dec_message: bad sizes (strides/offsets must be multiples of 4 floats)");
+  const int N = B * L, KT = (K + 15) / 16;
+  dim3 grid(edge_grid(N, MPNN_MSG_WAVES)), block(MPNN_MSG_WAVES * 64);
+  KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, true>), grid, block, 0, (hipStream_t)stream,
+                                     (const f32x4*)hE_frag, PQ, ldpq, offPa, PQ, ldpq, offA, PVenc, ldenc, offEnc, rank,
+                                     E_idx32, mask, edge_mask, (const f32x4*)W1b_packed, (const f32x4*)W2_packed, b2,
+                                     N, L, K, gsum, (float*)nullptr));
+  MPNN_LAUNCH_CHECK();
+}

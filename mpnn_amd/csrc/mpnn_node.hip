@@ -1,0 +1,208 @@
+// Per-node kernels for gfx950: node update (W3, LayerNorms, FFN) + the projections the next edge kernel
+// gathers, occupancy MLP, output head
+// (reference: src/mpnn/models/model_utils.py :81-88, :127-137, :151-155, :414-421, :527-528).
+#include "mpnn_common.h"
+
+// ---------------------------------------------------------------------------
+// node update + projections: one wavefront per 16 nodes, all weights streamed from L2.
+//   dh  = (W3 gsum + cnt b3) / scale                               (:78-81 with W3 hoisted)
+//   x   = LN1(h + dh);  y = LN2(x + W_out gelu(W_in x + b_in) + b_out);  h' = mask * y   (:82-88)
+//   PQ  = Wproj h' + bproj      (nproj blocks of 128 outputs: the next kernels' P/Q terms)
+// do_update = 0 skips the update and only projects h.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, const float* __restrict__ cnt,
+              float cnt_const, const float* __restrict__ mask, const f32x4* __restrict__ W3,
+              const float* __restrict__ b3, const float* __restrict__ ln1w, const float* __restrict__ ln1b,
+              const f32x4* __restrict__ Win, const float* __restrict__ bin, const f32x4* __restrict__ Wout,
+              const float* __restrict__ bout, const float* __restrict__ ln2w, const float* __restrict__ ln2b,
+              float inv_scale, int do_update, const f32x4* __restrict__ Wproj, const float* __restrict__ bproj,
+              int nproj, const float* __restrict__ add_table, int ld_table, int off_table,
+              const long long* __restrict__ add_idx, int add_block, int N, float* __restrict__ hV_out,
+              float* __restrict__ PQ) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (tile * 16 >= N) return;
+  const int g = lane >> 4, col = lane & 15;
+  const int node = tile * 16 + col;
+  const bool live = node < N;
+  const int nd = live ? node : N - 1;
+
+  f32x4 h[MPNN_NT][1];
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t)
+    h[t][0] = *reinterpret_cast<const f32x4*>(hV_in + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+
+  if (do_update) {
+    f32x4 gs[MPNN_NT][1], dh[MPNN_NT][1];
+    const float cn = cnt ? cnt[nd] : cnt_const;
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      gs[t][0] = *reinterpret_cast<const f32x4*>(gsum + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+      dh[t][0] = *reinterpret_cast<const f32x4*>(b3 + 16 * t + 4 * g) * cn;
+    }
+    tile_gemm<1, MPNN_NT, 0, 8>(W3, lane, gs, dh);
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) h[t][0] = h[t][0] + dh[t][0] * inv_scale;
+    tile_layernorm<1>(h, ln1w, ln1b, lane);
+    // FFN
+    f32x4 hid[32][1];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) hid[t][0] = *reinterpret_cast<const f32x4*>(bin + 16 * t + 4 * g);
+    tile_gemm<1, MPNN_NT, 0, 32>(Win, lane, h, hid);
+    tile_gelu<32, 1>(hid);
+    f32x4 o[MPNN_NT][1];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) o[t][0] = h[t][0] + *reinterpret_cast<const f32x4*>(bout + 16 * t + 4 * g);
+    tile_gemm<1, 32, 0, 8>(Wout, lane, hid, o);
+    tile_layernorm<1>(o, ln2w, ln2b, lane);
+    const float mk = mask[nd];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      h[t][0] = o[t][0] * mk;
+      if (live) *reinterpret_cast<f32x4*>(hV_out + (size_t)node * MPNN_H + 16 * t + 4 * g) = h[t][0];
+    }
+  }
+  const int ld = nproj * MPNN_H;
+  for (int p = 0; p < nproj; ++p) {
+    f32x4 y[MPNN_NT][1];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) y[t][0] = *reinterpret_cast<const f32x4*>(bproj + p * MPNN_H + 16 * t + 4 * g);
+    tile_gemm<1, MPNN_NT, 0, 8>(Wproj + (size_t)p * 4096, lane, h, y);
+    if (add_table && p == add_block) {  // decoder: fold the sequence term W1c W_s[S_n] into the PV block
+      const float* tr = add_table + (size_t)add_idx[nd] * ld_table + off_table + 4 * g;
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t) y[t][0] += *reinterpret_cast<const f32x4*>(tr + 16 * t);
+    }
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+        *reinterpret_cast<f32x4*>(PQ + (size_t)node * ld + p * MPNN_H + 16 * t + 4 * g) = y[t][0];
+    }
+  }
+}
+
+// occupancy MLP: h_V = LN(W2 gelu(w0 * occ + b0) + b2)   (reference :414-421, :461-462)
+__global__ void __launch_bounds__(256)
+k_occupancy_mlp(const float* __restrict__ occ, const float* __restrict__ w0, const float* __restrict__ b0,
+                const f32x4* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ lnw,
+                const float* __restrict__ lnb, int N, float* __restrict__ hV) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (tile * 16 >= N) return;
+  const int g = lane >> 4, col = lane & 15;
+  const int node = tile * 16 + col;
+  const bool live = node < N;
+  const float o = occ[live ? node : N - 1];
+  f32x4 x[MPNN_NT][1], y[MPNN_NT][1];
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) {
+    const f32x4 w = *reinterpret_cast<const f32x4*>(w0 + 16 * t + 4 * g);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(b0 + 16 * t + 4 * g);
+    x[t][0] = gelu4(w * o + bb);
+    y[t][0] = *reinterpret_cast<const f32x4*>(b2 + 16 * t + 4 * g);
+  }
+  tile_gemm<1, MPNN_NT, 0, 8>(W2, lane, x, y);
+  tile_layernorm<1>(y, lnw, lnb, lane);
+  if (live) {
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) *reinterpret_cast<f32x4*>(hV + (size_t)node * MPNN_H + 16 * t + 4 * g) = y[t][0];
+  }
+}
+
+// output head: log_softmax(W_out h + b) over n_letters <= 32 (reference :527-528)
+__global__ void __launch_bounds__(256)
+k_logits(const float* __restrict__ hV, const f32x4* __restrict__ Wp, const float* __restrict__ bias, int n_letters,
+         int N, float* __restrict__ log_probs) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (tile * 16 >= N) return;
+  const int g = lane >> 4, col = lane & 15;
+  const int node = tile * 16 + col;
+  const bool live = node < N;
+  const int nd = live ? node : N - 1;
+  f32x4 h[MPNN_NT][1], y[2][1];
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) h[t][0] = *reinterpret_cast<const f32x4*>(hV + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int letter = 16 * t + 4 * g + r;
+      y[t][0][r] = letter < n_letters ? bias[letter] : 0.f;
+    }
+  tile_gemm<1, MPNN_NT, 0, 2>(Wp, lane, h, y);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (16 * t + 4 * g + r < n_letters) mx = fmaxf(mx, y[t][0][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float se = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (16 * t + 4 * g + r < n_letters) se += expf(y[t][0][r] - mx);
+  se = quarter_sum(se);
+  const float lse = mx + logf(se);
+  if (live) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int letter = 16 * t + 4 * g + r;
+        if (letter < n_letters) log_probs[(size_t)node * n_letters + letter] = y[t][0][r] - lse;
+      }
+  }
+}
+
+// ===========================================================================
+// C ABI launchers
+// ===========================================================================
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+extern "C" int mpnn_node_update(const float* hV_in, const float* gsum, const float* cnt, float cnt_const,
+                                const float* mask, const float* W3_packed, const float* b3, const float* ln1_w,
+                                const float* ln1_b, const float* Win_packed, const float* b_in,
+                                const float* Wout_packed, const float* b_out, const float* ln2_w, const float* ln2_b,
+                                float scale, int do_update, const float* Wproj_packed, const float* bproj, int nproj,
+                                const float* add_table, int ld_table, int off_table, const int64_t* add_idx,
+                                int add_block, int n_nodes, float* hV_out, float* PQ, void* stream) {
+  MPNN_CHECK_ARG(hV_in && n_nodes > 0 && nproj >= 0, "mpnn_node_update: bad arguments");
+  if (do_update)
+    MPNN_CHECK_ARG(gsum && mask && W3_packed && b3 && ln1_w && ln1_b && Win_packed && b_in && Wout_packed && b_out &&
+                       ln2_w && ln2_b && hV_out && scale != 0.f,
+                   "mpnn_node_update: null pointer in update");
+  if (nproj > 0) MPNN_CHECK_ARG(Wproj_packed && bproj && PQ, "mpnn_node_update: null pointer in projection");
+  if (add_table)
+    MPNN_CHECK_ARG(add_idx && add_block >= 0 && add_block < nproj && ((ld_table | off_table) & 3) == 0,
+                   "mpnn_node_update: bad table-add arguments");
+  hipLaunchKernelGGL(k_node_update, dim3(ceil_div(n_nodes, 64)), dim3(256), 0, (hipStream_t)stream, hV_in, gsum, cnt,
+                     cnt_const, mask, (const f32x4*)W3_packed, b3, ln1_w, ln1_b, (const f32x4*)Win_packed, b_in,
+                     (const f32x4*)Wout_packed, b_out, ln2_w, ln2_b, 1.0f / scale, do_update,
+                     (const f32x4*)Wproj_packed, bproj, nproj, add_table, ld_table, off_table,
+                     (const long long*)add_idx, add_block, n_nodes, hV_out, PQ);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_occupancy_mlp(const float* occ, const float* w0, const float* b0, const float* W2_packed,
+                                  const float* b2, const float* ln_w, const float* ln_b, int n_nodes, float* hV,
+                                  void* stream) {
+  MPNN_CHECK_ARG(occ && w0 && b0 && W2_packed && b2 && ln_w && ln_b && hV && n_nodes > 0,
+                 "mpnn_occupancy_mlp: bad arguments");
+  hipLaunchKernelGGL(k_occupancy_mlp, dim3(ceil_div(n_nodes, 64)), dim3(256), 0, (hipStream_t)stream, occ, w0, b0,
+                     (const f32x4*)W2_packed, b2, ln_w, ln_b, n_nodes, hV);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_logits_log_softmax(const float* hV, const float* Wout_packed, const float* bias, int n_letters,
+                                       int n_nodes, float* log_probs, void* stream) {
+  MPNN_CHECK_ARG(hV && Wout_packed && bias && log_probs && n_nodes > 0 && n_letters >= 1 && n_letters <= 32,
+                 "mpnn_logits_log_softmax: bad arguments (n_letters <= 32)");
+  hipLaunchKernelGGL(k_logits, dim3(ceil_div(n_nodes, 64)), dim3(256), 0, (hipStream_t)stream, hV,
+                     (const f32x4*)Wout_packed, bias, n_letters, n_nodes, log_probs);
+  MPNN_LAUNCH_CHECK();
+}

@@ -113,10 +113,10 @@ class PackedWeights:
         def enc_upd_blocks(l):  # P' = W11a h + b11 ; Q' = W11c h
             return [(enc[l].W11.weight, 0, enc[l].W11.bias), (enc[l].W11.weight, 2 * H, None)]
 
-        def dec_first_blocks():  # Pa_0, PV_0 (= PVenc_0), PVenc_1, ...
+        def dec_first_blocks():  # Pa_0, A_0 (= W1d_0 h + TS_0[S], table added by the kernel), PVenc_0, PVenc_1, ...
             if not dec:
                 return []
-            blocks = [(dec[0].W1.weight, 0, dec[0].W1.bias)]
+            blocks = [(dec[0].W1.weight, 0, dec[0].W1.bias), (dec[0].W1.weight, 3 * H, None)]
             blocks += [(d_.W1.weight, 3 * H, None) for d_ in dec]
             return blocks
 
@@ -138,7 +138,8 @@ class PackedWeights:
             g_ts = proj_group([(d_.W1.weight, 2 * H, None) for d_ in dec])
             self.TS = torch.empty(self.n_vocab, len(dec) * H, device=dev, dtype=torch.float32)
             call("mpnn_node_update", ptr(self.Ws), None, None, 0.0, None, None, None, None, None, None, None, None,
-                 None, None, None, 1.0, 0, ptr(g_ts[0]), ptr(g_ts[1]), g_ts[2], self.n_vocab, None, ptr(self.TS), st)
+                 None, None, None, 1.0, 0, ptr(g_ts[0]), ptr(g_ts[1]), g_ts[2], None, 0, 0, None, 0, self.n_vocab,
+                 None, ptr(self.TS), st)
             self._keep.append(g_ts)
         self.Wlogit, self.blogit = pack(model.W_out.weight), vec(model.W_out.bias)
         self.n_letters = model.W_out.weight.shape[0]
@@ -261,16 +262,18 @@ class _FeaturePack:
 # ---------------------------------------------------------------------------
 # node kernel wrapper
 # ---------------------------------------------------------------------------
-def _node_update(hV_in, n_nodes, lw, gsum, cnt, cnt_const, mask, group, hV_out, PQ):
+def _node_update(hV_in, n_nodes, lw, gsum, cnt, cnt_const, mask, group, hV_out, PQ, table=None):
+    """table = (TS, ld, off, S, block): adds TS[S[n]][off:off+128] to projection block `block`."""
     Wp, bp, nproj = group
+    tb = (ptr(table[0]), table[1], table[2], ptr(table[3]), table[4]) if table is not None else (None, 0, 0, None, 0)
     if lw is None:
         call("mpnn_node_update", ptr(hV_in), None, None, 0.0, None, None, None, None, None, None, None, None, None,
-             None, None, 1.0, 0, ptr(Wp), ptr(bp), nproj, n_nodes, None, ptr(PQ), stream_ptr())
+             None, None, 1.0, 0, ptr(Wp), ptr(bp), nproj, *tb, n_nodes, None, ptr(PQ), stream_ptr())
     else:
         call("mpnn_node_update", ptr(hV_in), ptr(gsum), ptr(cnt), float(cnt_const), ptr(mask), ptr(lw["W3"]),
              ptr(lw["b3"]), ptr(lw["ln1w"]), ptr(lw["ln1b"]), ptr(lw["Win"]), ptr(lw["bin"]), ptr(lw["Wout"]),
-             ptr(lw["bout"]), ptr(lw["ln2w"]), ptr(lw["ln2b"]), lw["scale"], 1, ptr(Wp), ptr(bp), nproj, n_nodes,
-             ptr(hV_out), ptr(PQ), stream_ptr())
+             ptr(lw["bout"]), ptr(lw["ln2w"]), ptr(lw["ln2b"]), lw["scale"], 1, ptr(Wp), ptr(bp), nproj, *tb,
+             n_nodes, ptr(hV_out), ptr(PQ), stream_ptr())
 
 
 # ---------------------------------------------------------------------------
@@ -314,11 +317,17 @@ def forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_ord
     def new_pq(group):
         return torch.empty(N, max(group[2], 1) * H, device=dev, dtype=torch.float32) if group[2] else None
 
+    n_enc, n_dec = len(pw.enc), len(pw.dec)
+    ldts = pw.TS.shape[1] if pw.TS is not None else 0
+
+    def dec_table(layer, block):  # adds TS_layer[S] to projection block `block` (the decoder's A rows)
+        return (pw.TS, ldts, H * layer, S, block) if n_dec else None
+
     PQ = new_pq(pw.g_init)
     if pw.g_init[2]:
-        _node_update(hV, N, None, None, None, 0.0, None, pw.g_init, None, PQ)
+        _node_update(hV, N, None, None, None, 0.0, None, pw.g_init, None, PQ,
+                     table=dec_table(0, 1) if (n_enc == 0 and n_dec) else None)
 
-    n_enc, n_dec = len(pw.enc), len(pw.dec)
     for l, lw in enumerate(pw.enc):
         ld = PQ.shape[1]
         offP, offQ = (0, H) if l == 0 else (2 * H, 3 * H)
@@ -327,7 +336,9 @@ def forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_ord
         grp = pw.g_enc[l]
         PQn = new_pq(grp)
         hVn = torch.empty_like(hV)
-        _node_update(hV, N, lw, gsum, cnt, 0.0, mask, grp, hVn, PQn)
+        last = l + 1 == n_enc
+        _node_update(hV, N, lw, gsum, cnt, 0.0, mask, grp, hVn, PQn,
+                     table=dec_table(0, 3) if (last and n_dec) else None)
         hV, PQ = hVn, PQn
         call("mpnn_enc_edge_update", ptr(hE), ptr(PQ), PQ.shape[1], 0, H, ptr(E_idx32), ptr(lw["W11b"]),
              ptr(lw["W12"]), ptr(lw["b12"]), ptr(lw["W13"]), ptr(lw["b13"]), ptr(lw["ln3w"]), ptr(lw["ln3b"]), B, L, K,
@@ -351,23 +362,24 @@ def forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_ord
             fw = torch.empty_like(bw)
             call("mpnn_order_masks", ptr(rank), ptr(E_idx64), ptr(mask), ptr(edge_mask), B, L, K, ptr(bw), ptr(fw), st)
             inter.update(mask_bw=bw, mask_fw=fw, order=order)
-        # PQ layout after the last encoder stage (or g_init when there is no encoder):
-        #   [P'|Q'|Pa_0|PV_0|PVenc_1|...] with encoder, [Pa_0|PV_0|PVenc_1|...] without
+        # projection buffer after the last encoder stage (g_init when there is no encoder):
+        #   [P' | Q' |] Pa_0 | A_0 | PVenc_0 | PVenc_1 | ...      (A_l = W1d_l h + W1c_l W_s[S])
         base = 2 * H if n_enc else 0
         PQenc = PQ
         ldenc = PQenc.shape[1]
-        PQd, offPa, offPV = PQenc, base, base + H
+        PQd, offPa, offA = PQenc, base, base + H
         for l, lw in enumerate(pw.dec):
-            call("mpnn_dec_message", ptr(hE), ptr(PQd), PQd.shape[1], offPa, offPV, ptr(PQenc), ldenc,
-                 base + H * (1 + l), ptr(pw.TS), pw.TS.shape[1], H * l, ptr(S), ptr(rank), ptr(E_idx32), ptr(mask),
-                 ptr(edge_mask), ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"]), B, L, K, ptr(gsum), st)
+            call("mpnn_dec_message", ptr(hE), ptr(PQd), PQd.shape[1], offPa, offA, ptr(PQenc), ldenc,
+                 base + 2 * H + H * l, ptr(rank), ptr(E_idx32), ptr(mask), ptr(edge_mask), ptr(lw["W1b"]),
+                 ptr(lw["W2"]), ptr(lw["b2"]), B, L, K, ptr(gsum), st)
             grp = pw.g_dec[l]
             PQn = new_pq(grp)
             hVn = torch.empty_like(hV)
-            _node_update(hV, N, lw, gsum, None, float(K), mask, grp, hVn, PQn)
+            _node_update(hV, N, lw, gsum, None, float(K), mask, grp, hVn, PQn,
+                         table=dec_table(l + 1, 1) if grp[2] else None)
             hV = hVn
             if PQn is not None:
-                PQd, offPa, offPV = PQn, 0, H
+                PQd, offPa, offA = PQn, 0, H
             if return_intermediates:
                 inter["h_V_dec"].append(hV.view(B, L, H))
 
