@@ -35,6 +35,11 @@ const char* mpnn_last_error(void);
  * zero padded.  Weight layout prep for every Linear on the path (:64-69, :112-114, :147-148, :212, :400, :412). */
 int mpnn_pack_linear(const float* W, int out_f, int in_f, int ld, int col0, float* packed, void* stream);
 
+/* Same, for the split-precision MFMA path (mpnn_common.h): every weight is stored as f16 hi + f16 lo
+ * (22 significant bits), packed[ceil(out/16)][ceil(in/32)][2][64][8 halfs].  A product a*b is evaluated on the
+ * f16 matrix pipe as a_lo b_hi + a_hi b_lo + a_hi b_hi with fp32 accumulation (relative error <= ~2^-21). */
+int mpnn_pack_linear_split(const float* W, int out_f, int in_f, int ld, int col0, void* packed, void* stream);
+
 /* PositionalEncodings as a table: table[d][p] = W[p][d] + bias[p]  (one_hot(d) @ W^T + b, :168-177). */
 int mpnn_pos_table(const float* W, const float* bias, int nbuckets /*66*/, int npos /*16*/, float* table,
                    void* stream);

@@ -106,6 +106,84 @@ __device__ __forceinline__ void tile_gemm(WPtr Wp, int lane, const f32x4 (&X)[NT
   }
 }
 
+// ---------------------------------------------------------------------------
+// Split-precision products on the matrix pipe.
+// MEASURED on MI355X (rocprofv3: SQ_VALU_MFMA_COEXEC_CYCLES == 0 and kernel time == MFMA busy + VALU busy):
+// the f32-input MFMA does not co-execute with VALU work and runs at the f32 vector rate, so every GELU /
+// LayerNorm instruction adds to an f32-MFMA kernel's time.  The f16 MFMA (v_mfma_f32_16x16x32_f16) is 16x
+// faster per MAC and does co-execute.  Each f32 operand is therefore split as x = hi + lo, hi = f16(x),
+// lo = f16(x - hi) (22 significant bits), and a product is evaluated as  a_lo b_hi + a_hi b_lo + a_hi b_hi
+// with fp32 accumulation inside the MFMA: relative error per product <= ~2^-21 (the dropped a_lo b_lo term
+// and the two 2^-23 representation residuals), i.e. fp32-class, at 3/16 of the f32-MFMA pipe time.
+// Operand range: |x| < 65504 (f16); values below 6e-5 keep 6e-8 ABSOLUTE resolution (f16 subnormals).
+//
+// k ordering of one k-step (32 features) = two consecutive feature tiles: lane quarter g holds, in element j
+// of its 8-half fragment, feature 16 (2 kk + (j >> 2)) + 4 g + (j & 3): exactly registers r = j & 3 of the
+// D tiles 2kk and 2kk+1 it already owns, so layers still chain without any cross-lane movement.
+// Packed weights: h8 Wp[to][kk][part(hi, lo)][lane]  (mpnn_pack_linear_split).
+// ---------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+struct BFrag {
+  h8 hi, lo;
+};
+
+__device__ __forceinline__ void split_pair(const f32x4 a, const f32x4 b, BFrag& o) {
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const _Float16 h = (_Float16)v[j];
+    o.hi[j] = h;
+    o.lo[j] = (_Float16)(v[j] - (float)h);
+  }
+}
+
+__device__ __forceinline__ f32x4 mfma_split(const h8 a_hi, const h8 a_lo, const BFrag& b, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b.hi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b.hi, acc, 0, 0, 0);
+  return acc;
+}
+
+// one k-step: Y[to][c] += W[to][kk] * B[c]  for to in [TO0, TO1)
+template <int KT, int NKK, int TO0, int TO1, typename WPtr>
+__device__ __forceinline__ void split_kstep(WPtr Wp, int kk, int lane, const BFrag (&B)[KT],
+                                            f32x4 (&Y)[TO1 - TO0][KT]) {
+#pragma unroll
+  for (int to = TO0; to < TO1; ++to) {
+    const h8 a_hi = Wp[((to * NKK + kk) * 2 + 0) * 64 + lane];
+    const h8 a_lo = Wp[((to * NKK + kk) * 2 + 1) * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) Y[to - TO0][c] = mfma_split(a_hi, a_lo, B[c], Y[to - TO0][c]);
+  }
+}
+
+// Y[to][c] += W[to][:] * X   with X given as NKK k-steps of B fragments
+template <int KT, int NKK, int TO0, int TO1, typename WPtr>
+__device__ __forceinline__ void split_gemm(WPtr Wp, int lane, const BFrag (&B)[NKK][KT], f32x4 (&Y)[TO1 - TO0][KT]) {
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) {
+    split_kstep<KT, NKK, TO0, TO1>(Wp, kk, lane, B[kk], Y);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// fp32 register tile (NT_ feature tiles) -> NT_/2 k-steps of B fragments, optionally through GELU
+template <int NT_, int KT, bool GELU>
+__device__ __forceinline__ void tile_to_bfrag(const f32x4 (&V)[NT_][KT], BFrag (&B)[NT_ / 2][KT]) {
+#pragma unroll
+  for (int kk = 0; kk < NT_ / 2; ++kk) {
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      if (GELU)
+        split_pair(gelu4(V[2 * kk][c]), gelu4(V[2 * kk + 1][c]), B[kk][c]);
+      else
+        split_pair(V[2 * kk][c], V[2 * kk + 1][c], B[kk][c]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // LayerNorm over the 128 features of each column, in place.
 //   V[t][c] holds features 16t + 4g + r of column c; gamma/beta are [128] in global/LDS.
 template <int KT>

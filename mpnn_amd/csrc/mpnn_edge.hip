@@ -34,58 +34,55 @@
 #define LAUNDER(p) asm volatile("" : "+s"(p))
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 
-__device__ __forceinline__ void lds_fill(f32x4* dst, const f32x4* __restrict__ src, int n4) {
-  for (int i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+__device__ __forceinline__ void lds_fill(h8* dst, const h8* __restrict__ src, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
 __device__ __forceinline__ f32x4 row_tile(const float* row, int t) {
   return *reinterpret_cast<const f32x4*>(row + 16 * t);
 }
 
-// acc[to][c] += W[to][ti] * x[c]  for to in [TO0, TO1) at one k-tile ti (weights in LDS)
-template <int KT, int TO0, int TO1>
-__device__ __forceinline__ void mfma_ktile(const f32x4* Ws, int ti, int lane, const f32x4 (&x)[KT],
-                                           f32x4 (&acc)[TO1 - TO0][KT]) {
-#pragma unroll
-  for (int to = TO0; to < TO1; ++to) {
-    const f32x4 a = Ws[(to * MPNN_NT + ti) * 64 + lane];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < KT; ++c) acc[to - TO0][c] = mfma4(a[r], x[c][r], acc[to - TO0][c]);
-  }
-}
+constexpr int NKK = MPNN_NT / 2;       // k-steps (32 features) per 128-wide layer
+constexpr int WSPLIT = 8 * NKK * 2 * 64;  // h8 elements of one packed 128x128 matrix (64 KiB)
 
-// layer 1 of every edge MLP: acc += W1b * hE[node], hE k-tiles double-buffered from HBM
+// layer 1 of every edge MLP: acc += W1b * hE[node]; hE feature tiles stream from HBM one k-step
+// (two tiles) ahead of their MFMAs and are split to f16 hi/lo on the fly
 template <int KT>
-__device__ __forceinline__ void layer1_stream(const f32x4* Ws, const f32x4* __restrict__ x, int lane,
+__device__ __forceinline__ void layer1_stream(const h8* Ws, const f32x4* __restrict__ x, int lane,
                                               f32x4 (&acc)[MPNN_NT][KT]) {
-  f32x4 xb[2][KT];
+  f32x4 xb[2][2][KT];
 #pragma unroll
-  for (int c = 0; c < KT; ++c) xb[0][c] = x[c * 64];
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
-  for (int ti = 0; ti < MPNN_NT; ++ti) {
-    if (ti + 1 < MPNN_NT) {
+    for (int c = 0; c < KT; ++c) xb[0][u][c] = x[(u * KT + c) * 64];
 #pragma unroll
-      for (int c = 0; c < KT; ++c) xb[(ti + 1) & 1][c] = x[((ti + 1) * KT + c) * 64];
+  for (int kk = 0; kk < NKK; ++kk) {
+    if (kk + 1 < NKK) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) xb[(kk + 1) & 1][u][c] = x[((2 * (kk + 1) + u) * KT + c) * 64];
     }
-    mfma_ktile<KT, 0, MPNN_NT>(Ws, ti, lane, xb[ti & 1], acc);
+    BFrag b[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) split_pair(xb[kk & 1][0][c], xb[kk & 1][1][c], b[c]);
+    split_kstep<KT, NKK, 0, MPNN_NT>(Ws, kk, lane, b, acc);
     FENCE();
   }
 }
 
-// masked neighbour sum of gelu(y) over the residue's edges -> gsum tile rows [T0, T0+4)
+// masked neighbour sum of gelu(y) over the residue's edges -> gsum
 template <int KT>
-__device__ __forceinline__ void reduce_store(f32x4 (&y)[4][KT], const float (&w)[KT], float* __restrict__ out,
-                                             int T0, int lane) {
+__device__ __forceinline__ void reduce_store(f32x4 (&y)[MPNN_NT][KT], const float (&w)[KT], float* __restrict__ out,
+                                             int lane) {
   const int g = lane >> 4, col = lane & 15;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < MPNN_NT; ++t) {
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < KT; ++c) s += gelu4(y[t][c]) * w[c];
     s.x = column_sum(s.x); s.y = column_sum(s.y); s.z = column_sum(s.z); s.w = column_sum(s.w);
-    if (col == 0) *reinterpret_cast<f32x4*>(out + 16 * (T0 + t) + 4 * g) = s;
+    if (col == 0) *reinterpret_cast<f32x4*>(out + 16 * t + 4 * g) = s;
     FENCE();
   }
 }
@@ -102,14 +99,14 @@ __global__ void __launch_bounds__(MPNN_MSG_WAVES * 64)
 k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp, int offP,
           const float* __restrict__ Abuf, int lda, int offA, const float* __restrict__ Bbuf, int ldb, int offB,
           const int* __restrict__ rank, const int* __restrict__ E_idx, const float* __restrict__ mask,
-          const float* __restrict__ edge_mask, const f32x4* __restrict__ W1b, const f32x4* __restrict__ W2,
+          const float* __restrict__ edge_mask, const h8* __restrict__ W1b, const h8* __restrict__ W2,
           const float* __restrict__ b2, int N, int L, int K, float* __restrict__ gsum, float* __restrict__ cnt) {
-  __shared__ f32x4 lds[2 * 64 * 64];
-  lds_fill(lds, W1b, 4096);
-  lds_fill(lds + 4096, W2, 4096);
+  __shared__ h8 lds[2 * WSPLIT];
+  lds_fill(lds, W1b, WSPLIT);
+  lds_fill(lds + WSPLIT, W2, WSPLIT);
   __syncthreads();
-  const f32x4* W1s = lds;
-  const f32x4* W2s = lds + 4096;
+  const h8* W1s = lds;
+  const h8* W2s = lds + WSPLIT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, col = lane & 15;
   constexpr int Kp = KT * 16;
@@ -154,8 +151,7 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
   for (; node < N; node += stride) {
     const int nxt = (node + stride < N) ? node + stride : N - 1;  // tail: harmless re-load of a valid residue
     LAUNDER(b2);
-    // P_i: needed only after layer 1
-    f32x4 p[MPNN_NT];
+    f32x4 p[MPNN_NT];  // P_i: needed only after layer 1
     {
       const float* Pi = Pbuf + (size_t)node * ldp + offP + 4 * g;
 #pragma unroll
@@ -163,50 +159,29 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
     }
     layer1_stream<KT>(W1s, hE + (size_t)node * (MPNN_NT * KT * 64) + lane, lane, h1);
 #pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t) {
+    for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-      for (int c = 0; c < KT; ++c) h1[t][c] = gelu4(DEC ? (h1[t][c] * s[c] + p[t]) : (h1[t][c] + p[t]));
-      FENCE();
-    }
-    // next residue's scalars (their loads fly under layer 2, first half)
+      for (int c = 0; c < KT; ++c) h1[t][c] = DEC ? (h1[t][c] * s[c] + p[t]) : (h1[t][c] + p[t]);
+    BFrag hb[NKK][KT];
+    tile_to_bfrag<MPNN_NT, KT, true>(h1, hb);
+    // next residue's scalars (their loads fly under layer 2)
     const float* rown[KT];
     float sn[KT], wn[KT];
     setup(nxt, rown, sn, wn);
-    float* gout = gsum + (size_t)node * MPNN_H;
-    // ---- layer 2, output rows 0..63
-    {
-      f32x4 y[4][KT];
+    f32x4 y[MPNN_NT][KT];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + 16 * t + 4 * g);
+    for (int t = 0; t < MPNN_NT; ++t) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + 16 * t + 4 * g);
 #pragma unroll
-        for (int c = 0; c < KT; ++c) y[t][c] = bb;
-      }
-#pragma unroll
-      for (int ti = 0; ti < MPNN_NT; ++ti) {
-        mfma_ktile<KT, 0, 4>(W2s, ti, lane, h1[ti], y);
-        FENCE();
-      }
-      reduce_store<KT>(y, w, gout, 0, lane);
+      for (int c = 0; c < KT; ++c) y[t][c] = bb;
     }
-    // ---- layer 2, output rows 64..127; each h1 tile is refilled with the next residue's row once consumed
-    {
-      f32x4 y[4][KT];
+    split_gemm<KT, NKK, 0, MPNN_NT>(W2s, lane, hb, y);
+    // h1 is free: gather the next residue's rows under the GELU + reduction below
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + 16 * (4 + t) + 4 * g);
+    for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-        for (int c = 0; c < KT; ++c) y[t][c] = bb;
-      }
-#pragma unroll
-      for (int ti = 0; ti < MPNN_NT; ++ti) {
-        mfma_ktile<KT, 4, 8>(W2s, ti, lane, h1[ti], y);
-        FENCE();
-#pragma unroll
-        for (int c = 0; c < KT; ++c) h1[ti][c] = row_tile(rown[c], ti);
-      }
-      reduce_store<KT>(y, w, gout, 4, lane);
-    }
+      for (int c = 0; c < KT; ++c) h1[t][c] = row_tile(rown[c], t);
+    reduce_store<KT>(y, w, gsum + (size_t)node * MPNN_H, lane);
     if (!DEC) {
       float csum = 0.f;
 #pragma unroll
@@ -225,20 +200,20 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 // ---------------------------------------------------------------------------
 // encoder edge update, in place on hE (reference :90-95; unmasked):
 //   e_ik <- LN3(e_ik + W13 gelu(W12 gelu(P'_i + Q'_j + W11b e_ik) + b12) + b13)
-// W11b, W12 in LDS; W13 streams from L2 (A fragments three ahead of their MFMAs).
+// W11b, W12 in LDS; W13 streams from L2 (A fragments three steps ahead of their MFMAs).
 // ---------------------------------------------------------------------------
 template <int KT>
 __global__ void __launch_bounds__(MPNN_UPD_WAVES * 64)
 k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ PQ, int ldpq, int offP, int offQ,
-                  const int* __restrict__ E_idx, const f32x4* __restrict__ W11b, const f32x4* __restrict__ W12,
-                  const float* __restrict__ b12, const f32x4* __restrict__ W13, const float* __restrict__ b13,
+                  const int* __restrict__ E_idx, const h8* __restrict__ W11b, const h8* __restrict__ W12,
+                  const float* __restrict__ b12, const h8* __restrict__ W13, const float* __restrict__ b13,
                   const float* __restrict__ ln_w, const float* __restrict__ ln_b, int N, int L) {
-  __shared__ f32x4 lds[2 * 64 * 64];
-  lds_fill(lds, W11b, 4096);
-  lds_fill(lds + 4096, W12, 4096);
+  __shared__ h8 lds[2 * WSPLIT];
+  lds_fill(lds, W11b, WSPLIT);
+  lds_fill(lds + WSPLIT, W12, WSPLIT);
   __syncthreads();
-  const f32x4* W1s = lds;
-  const f32x4* W2s = lds + 4096;
+  const h8* W1s = lds;
+  const h8* W2s = lds + WSPLIT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, col = lane & 15;
   constexpr int Kp = KT * 16;
@@ -267,9 +242,9 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ PQ, int ldpq
     LAUNDER(b13);
     LAUNDER(ln_w);
     LAUNDER(ln_b);
-    const f32x4* W3u = W13;
+    const h8* W3u = W13;
     LAUNDER(W3u);
-    const f32x4* W3g = W3u + lane;
+    const h8* W3g = W3u + lane;
     f32x4* x = hE + (size_t)node * (MPNN_NT * KT * 64) + lane;
     f32x4 p[MPNN_NT];
     {
@@ -284,57 +259,56 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ PQ, int ldpq
       for (int c = 0; c < KT; ++c) h1[t][c] = h2[t][c];
     layer1_stream<KT>(W1s, x, lane, h1);
 #pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t) {
+    for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-      for (int c = 0; c < KT; ++c) h1[t][c] = gelu4(h1[t][c] + p[t]);
-      FENCE();
-    }
+      for (int c = 0; c < KT; ++c) h1[t][c] += p[t];
+    BFrag hb[NKK][KT];
+    tile_to_bfrag<MPNN_NT, KT, true>(h1, hb);
     const float* rown[KT];
     setup(nxt, rown);
-    // ---- layer 2; each consumed h1 tile is refilled with the residual e (layer 3's initial accumulator)
+    // ---- layer 2
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
       const f32x4 bb = *reinterpret_cast<const f32x4*>(b12 + 16 * t + 4 * g);
 #pragma unroll
       for (int c = 0; c < KT; ++c) h2[t][c] = bb;
     }
+    split_gemm<KT, NKK, 0, MPNN_NT>(W2s, lane, hb, h2);
+    // residual e -> layer 3's initial accumulator (loads fly under the GELU + split of h2)
 #pragma unroll
-    for (int ti = 0; ti < MPNN_NT; ++ti) {
-      mfma_ktile<KT, 0, MPNN_NT>(W2s, ti, lane, h1[ti], h2);
-      FENCE();
+    for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-      for (int c = 0; c < KT; ++c) h1[ti][c] = x[(ti * KT + c) * 64];
-    }
-#pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t) {
-#pragma unroll
-      for (int c = 0; c < KT; ++c) h2[t][c] = gelu4(h2[t][c]);
-      FENCE();
-    }
-    // ---- layer 3 on top of the residual; W13 fragments from L2, three ahead
+      for (int c = 0; c < KT; ++c) h1[t][c] = x[(t * KT + c) * 64];
+    tile_to_bfrag<MPNN_NT, KT, true>(h2, hb);
+    // ---- layer 3; W13 fragments (hi, lo) from L2, D steps ahead.  step q = kk * 8 + to
     {
       constexpr int D = 3;
-      f32x4 a[D + 1];
+      h8 ah[D + 1], al[D + 1];
 #pragma unroll
-      for (int q = 0; q < D; ++q) a[q] = W3g[((q & 7) * MPNN_NT + (q >> 3)) * 64];  // q = ti*8 + to
+      for (int q = 0; q < D; ++q) {
+        ah[q] = W3g[(((q & 7) * NKK + (q >> 3)) * 2 + 0) * 64];
+        al[q] = W3g[(((q & 7) * NKK + (q >> 3)) * 2 + 1) * 64];
+      }
 #pragma unroll
-      for (int ti = 0; ti < MPNN_NT; ++ti) {
+      for (int kk = 0; kk < NKK; ++kk) {
 #pragma unroll
         for (int to = 0; to < MPNN_NT; ++to) {
-          const int q = ti * MPNN_NT + to;
-          if (q + D < 64) a[(q + D) % (D + 1)] = W3g[(((q + D) & 7) * MPNN_NT + ((q + D) >> 3)) * 64];
-          const f32x4 aa = a[q % (D + 1)];
+          const int q = kk * MPNN_NT + to, qn = q + D;
+          if (qn < NKK * MPNN_NT) {
+            ah[qn % (D + 1)] = W3g[(((qn & 7) * NKK + (qn >> 3)) * 2 + 0) * 64];
+            al[qn % (D + 1)] = W3g[(((qn & 7) * NKK + (qn >> 3)) * 2 + 1) * 64];
+          }
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < KT; ++c) h1[to][c] = mfma4(aa[r], h2[ti][c][r], h1[to][c]);
+          for (int c = 0; c < KT; ++c) h1[to][c] = mfma_split(ah[q % (D + 1)], al[q % (D + 1)], hb[kk][c], h1[to][c]);
         }
         FENCE();
-        // h2[ti] is dead: start gathering the next residue's Q' rows into it
-#pragma unroll
-        for (int c = 0; c < KT; ++c) h2[ti][c] = row_tile(rown[c], ti);
       }
     }
+    // next residue's Q' rows -> h2 (carried to the next iteration), under LayerNorm + store
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) h2[t][c] = row_tile(rown[c], t);
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
       const f32x4 bb = *reinterpret_cast<const f32x4*>(b13 + 16 * t + 4 * g);
@@ -388,8 +362,8 @@ extern "C" int mpnn_enc_message(const float* hE_frag, const float* PQ, int ldpq,
   dim3 grid(edge_grid(N, MPNN_MSG_WAVES)), block(MPNN_MSG_WAVES * 64);
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, false>), grid, block, 0, (hipStream_t)stream,
                                      (const f32x4*)hE_frag, PQ, ldpq, offP, PQ, ldpq, offQ, (const float*)nullptr, 0, 0,
-                                     (const int*)nullptr, E_idx32, mask, edge_mask, (const f32x4*)W1b_packed,
-                                     (const f32x4*)W2_packed, b2, N, L, K, gsum, cnt));
+                                     (const int*)nullptr, E_idx32, mask, edge_mask, (const h8*)W1b_packed,
+                                     (const h8*)W2_packed, b2, N, L, K, gsum, cnt));
   MPNN_LAUNCH_CHECK();
 }
 
@@ -404,8 +378,8 @@ extern "C" int mpnn_enc_edge_update(float* hE_frag, const float* PQ, int ldpq, i
   const int N = B * L, KT = (K + 15) / 16;
   dim3 grid(edge_grid(N, MPNN_UPD_WAVES)), block(MPNN_UPD_WAVES * 64);
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_enc_edge_update<kKT>), grid, block, 0, (hipStream_t)stream, (f32x4*)hE_frag, PQ,
-                                     ldpq, offP, offQ, E_idx32, (const f32x4*)W11b_packed, (const f32x4*)W12_packed,
-                                     b12, (const f32x4*)W13_packed, b13, ln_w, ln_b, N, L));
+                                     ldpq, offP, offQ, E_idx32, (const h8*)W11b_packed, (const h8*)W12_packed,
+                                     b12, (const h8*)W13_packed, b13, ln_w, ln_b, N, L));
   MPNN_LAUNCH_CHECK();
 }
 
@@ -422,7 +396,7 @@ extern "C" int mpnn_dec_message(const float* hE_frag, const float* PQ, int ldpq,
   dim3 grid(edge_grid(N, MPNN_MSG_WAVES)), block(MPNN_MSG_WAVES * 64);
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, true>), grid, block, 0, (hipStream_t)stream,
                                      (const f32x4*)hE_frag, PQ, ldpq, offPa, PQ, ldpq, offA, PVenc, ldenc, offEnc, rank,
-                                     E_idx32, mask, edge_mask, (const f32x4*)W1b_packed, (const f32x4*)W2_packed, b2,
+                                     E_idx32, mask, edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2,
                                      N, L, K, gsum, (float*)nullptr));
   MPNN_LAUNCH_CHECK();
 }

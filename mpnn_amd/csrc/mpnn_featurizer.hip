@@ -226,6 +226,27 @@ __global__ void k_pack_linear(const float* __restrict__ W, int out_f, int in_f, 
   reinterpret_cast<f32x4*>(packed)[idx] = v;
 }
 
+// split-f16 packing (see mpnn_common.h): packed[to][kk][part][lane] is an h8 whose element j is the hi (part 0)
+// or lo (part 1) half of W[16 to + (lane&15)][col0 + 16 (2 kk + (j>>2)) + 4 (lane>>4) + (j&3)]
+__global__ void k_pack_linear_split(const float* __restrict__ W, int out_f, int in_f, int ld, int col0,
+                                    h8* __restrict__ packed, int nto, int nkk) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one (to, kk, lane)
+  if (idx >= nto * nkk * 64) return;
+  const int lane = idx & 63, kk = (idx >> 6) % nkk, to = (idx >> 6) / nkk;
+  const int row = 16 * to + (lane & 15);
+  h8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int col = 16 * (2 * kk + (j >> 2)) + 4 * (lane >> 4) + (j & 3);
+    const float w = (row < out_f && col < in_f) ? W[(size_t)row * ld + col0 + col] : 0.f;
+    const _Float16 h = (_Float16)w;
+    hi[j] = h;
+    lo[j] = (_Float16)(w - (float)h);
+  }
+  packed[((to * nkk + kk) * 2 + 0) * 64 + lane] = hi;
+  packed[((to * nkk + kk) * 2 + 1) * 64 + lane] = lo;
+}
+
 // positional table: T[d][p] = W[p][d] + b[p]   (one_hot(d) @ W^T + b, :168-177)
 __global__ void k_pos_table(const float* __restrict__ W, const float* __restrict__ bias, int nbuckets, int npos,
                             float* __restrict__ T) {
@@ -462,6 +483,15 @@ extern "C" int mpnn_pack_linear(const float* W, int out_f, int in_f, int ld, int
   const int nto = (out_f + 15) / 16, nti = (in_f + 15) / 16;
   hipLaunchKernelGGL(k_pack_linear, dim3(ceil_div((long long)nto * nti * 64, 256)), dim3(256), 0, (hipStream_t)stream,
                      W, out_f, in_f, ld, col0, packed, nto, nti);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_pack_linear_split(const float* W, int out_f, int in_f, int ld, int col0, void* packed,
+                                      void* stream) {
+  MPNN_CHECK_ARG(W && packed && out_f > 0 && in_f > 0 && ld >= col0 + in_f, "mpnn_pack_linear_split: bad arguments");
+  const int nto = (out_f + 15) / 16, nkk = (in_f + 31) / 32;
+  hipLaunchKernelGGL(k_pack_linear_split, dim3(ceil_div((long long)nto * nkk * 64, 256)), dim3(256), 0,
+                     (hipStream_t)stream, W, out_f, in_f, ld, col0, (h8*)packed, nto, nkk);
   MPNN_LAUNCH_CHECK();
 }
 

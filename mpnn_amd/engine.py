@@ -58,6 +58,17 @@ class PackedWeights:
             call("mpnn_pack_linear", ptr(W), out_f, ncols, ld, col0, ptr(out), st)
             return out
 
+        def pack_split(W, col0=0, ncols=None):
+            """f16 hi/lo split packing for the matrix-pipe kernels: [out/16][in/32][2][64] x 16 B."""
+            W = _f32(W)
+            self._keep.append(W)
+            out_f, ld = W.shape
+            ncols = ld - col0 if ncols is None else ncols
+            nto, nkk = (out_f + 15) // 16, (ncols + 31) // 32
+            out = torch.empty(nto * nkk * 2 * 64 * 4, device=dev, dtype=torch.float32)  # 16 B per lane
+            call("mpnn_pack_linear_split", ptr(W), out_f, ncols, ld, col0, ptr(out), st)
+            return out
+
         def vec(b):
             return _f32(b)
 
@@ -88,17 +99,17 @@ class PackedWeights:
         enc, dec = list(model.encoder_layers), list(model.decoder_layers)
         self.enc, self.dec = [], []
         for lyr in enc:
-            d = dict(W1b=pack(lyr.W1.weight, H, H), W2=pack(lyr.W2.weight), b2=vec(lyr.W2.bias),
+            d = dict(W1b=pack_split(lyr.W1.weight, H, H), W2=pack_split(lyr.W2.weight), b2=vec(lyr.W2.bias),
                      W3=pack(lyr.W3.weight), b3=vec(lyr.W3.bias),
-                     W11b=pack(lyr.W11.weight, H, H), W12=pack(lyr.W12.weight), b12=vec(lyr.W12.bias),
-                     W13=pack(lyr.W13.weight), b13=vec(lyr.W13.bias),
+                     W11b=pack_split(lyr.W11.weight, H, H), W12=pack_split(lyr.W12.weight), b12=vec(lyr.W12.bias),
+                     W13=pack_split(lyr.W13.weight), b13=vec(lyr.W13.bias),
                      ln1w=vec(lyr.norm1.weight), ln1b=vec(lyr.norm1.bias), ln2w=vec(lyr.norm2.weight),
                      ln2b=vec(lyr.norm2.bias), ln3w=vec(lyr.norm3.weight), ln3b=vec(lyr.norm3.bias),
                      Win=pack(lyr.dense.W_in.weight), bin=vec(lyr.dense.W_in.bias),
                      Wout=pack(lyr.dense.W_out.weight), bout=vec(lyr.dense.W_out.bias), scale=float(lyr.scale))
             self.enc.append(d)
         for lyr in dec:
-            d = dict(W1b=pack(lyr.W1.weight, H, H), W2=pack(lyr.W2.weight), b2=vec(lyr.W2.bias),
+            d = dict(W1b=pack_split(lyr.W1.weight, H, H), W2=pack_split(lyr.W2.weight), b2=vec(lyr.W2.bias),
                      W3=pack(lyr.W3.weight), b3=vec(lyr.W3.bias),
                      ln1w=vec(lyr.norm1.weight), ln1b=vec(lyr.norm1.bias), ln2w=vec(lyr.norm2.weight),
                      ln2b=vec(lyr.norm2.bias),
@@ -427,10 +438,18 @@ def enc_layer_standalone(layer, h_V, h_E, E_idx, mask_V=None, mask_attend=None):
         bp = torch.cat([_f32(layer.W1.bias), torch.zeros(H, device=dev)])
         Wp2 = torch.cat([pack(layer.W11.weight, 0, H), pack(layer.W11.weight, 2 * H, H)])
         bp2 = torch.cat([_f32(layer.W11.bias), torch.zeros(H, device=dev)])
-        c = dict(key=key, g1=(Wp, bp, 2), g2=(Wp2, bp2, 2), W1b=pack(layer.W1.weight, H, H), W2=pack(layer.W2.weight),
+        def pack_split(W, col0=0, ncols=None):
+            W = _f32(W)
+            out_f, ld = W.shape
+            ncols = ld - col0 if ncols is None else ncols
+            out = torch.empty(((out_f + 15) // 16) * ((ncols + 31) // 32) * 512, device=dev, dtype=torch.float32)
+            call("mpnn_pack_linear_split", ptr(W), out_f, ncols, ld, col0, ptr(out), st)
+            return out
+        c = dict(key=key, g1=(Wp, bp, 2), g2=(Wp2, bp2, 2), W1b=pack_split(layer.W1.weight, H, H),
+                 W2=pack_split(layer.W2.weight),
                  b2=_f32(layer.W2.bias), W3=pack(layer.W3.weight), b3=_f32(layer.W3.bias),
-                 W11b=pack(layer.W11.weight, H, H), W12=pack(layer.W12.weight), b12=_f32(layer.W12.bias),
-                 W13=pack(layer.W13.weight), b13=_f32(layer.W13.bias), ln1w=_f32(layer.norm1.weight),
+                 W11b=pack_split(layer.W11.weight, H, H), W12=pack_split(layer.W12.weight), b12=_f32(layer.W12.bias),
+                 W13=pack_split(layer.W13.weight), b13=_f32(layer.W13.bias), ln1w=_f32(layer.norm1.weight),
                  ln1b=_f32(layer.norm1.bias), ln2w=_f32(layer.norm2.weight), ln2b=_f32(layer.norm2.bias),
                  ln3w=_f32(layer.norm3.weight), ln3b=_f32(layer.norm3.bias), Win=pack(layer.dense.W_in.weight),
                  bin=_f32(layer.dense.W_in.bias), Wout=pack(layer.dense.W_out.weight),
