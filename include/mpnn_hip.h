@@ -37,8 +37,11 @@ int mpnn_pack_linear(const float* W, int out_f, int in_f, int ld, int col0, floa
 
 /* Same, for the split-precision MFMA path (mpnn_common.h): every weight is stored as f16 hi + f16 lo
  * (22 significant bits), packed[ceil(out/16)][ceil(in/32)][2][64][8 halfs].  A product a*b is evaluated on the
- * f16 matrix pipe as a_lo b_hi + a_hi b_lo + a_hi b_hi with fp32 accumulation (relative error <= ~2^-21). */
-int mpnn_pack_linear_split(const float* W, int out_f, int in_f, int ld, int col0, void* packed, void* stream);
+ * f16 matrix pipe as a_lo b_hi + a_hi b_lo + a_hi b_hi with fp32 accumulation (relative error <= ~2^-21).
+ * rot rotates the input features (packed column c = source column (c + rot) mod in_f): the featurizer packs
+ * edge_embedding with rot = 16 so that the positional block comes after the RBF blocks. */
+int mpnn_pack_linear_split(const float* W, int out_f, int in_f, int ld, int col0, int rot, void* packed,
+                           void* stream);
 
 /* PositionalEncodings as a table: table[d][p] = W[p][d] + bias[p]  (one_hot(d) @ W^T + b, :168-177). */
 int mpnn_pos_table(const float* W, const float* bias, int nbuckets /*66*/, int npos /*16*/, float* table,

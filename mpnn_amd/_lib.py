@@ -21,7 +21,7 @@ _F = ctypes.c_float
 # name -> argtypes (all return int except where noted)
 SIGNATURES = {
     "mpnn_pack_linear": [_P, _I, _I, _I, _I, _P, _P],
-    "mpnn_pack_linear_split": [_P, _I, _I, _I, _I, _P, _P],
+    "mpnn_pack_linear_split": [_P, _I, _I, _I, _I, _I, _P, _P],
     "mpnn_pos_table": [_P, _P, _I, _I, _P, _P],
     "mpnn_backbone_atoms": [_P, _P, _P, _I, _I, _P, _P, _P],
     "mpnn_knn_topk": [_P, _I, _I, _I, _F, _P, _P, _P, _P, _P],

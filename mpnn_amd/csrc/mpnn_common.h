@@ -168,6 +168,53 @@ __device__ __forceinline__ void split_gemm(WPtr Wp, int lane, const BFrag (&B)[N
   }
 }
 
+// Weights streamed from L2 (global memory) instead of LDS: a ring of D+1 (hi, lo) fragment pairs keeps the
+// loads D steps ahead of their MFMAs.  Step q = kk * NTO + to; all indices fold to constants after unrolling.
+template <int D>
+struct WRing {
+  h8 hi[D + 1], lo[D + 1];
+};
+
+template <int NKK, int NTO, int D>
+__device__ __forceinline__ void wring_load(WRing<D>& r, const h8* __restrict__ Wlane, int q) {
+  // Wlane = packed base + lane; fragment (to, kk) lives at ((to * NKK + kk) * 2 + part) * 64
+  const int to = q % NTO, kk = q / NTO;
+  r.hi[q % (D + 1)] = Wlane[((to * NKK + kk) * 2 + 0) * 64];
+  r.lo[q % (D + 1)] = Wlane[((to * NKK + kk) * 2 + 1) * 64];
+}
+
+template <int NKK, int NTO, int D>
+__device__ __forceinline__ void wring_prologue(WRing<D>& r, const h8* __restrict__ Wlane) {
+#pragma unroll
+  for (int q = 0; q < D; ++q)
+    if (q < NKK * NTO) wring_load<NKK, NTO, D>(r, Wlane, q);
+}
+
+// one k-step with streamed weights: Y[to][c] += W[to][kk] * B[c], to in [0, NTO)
+template <int KT, int NKK, int NTO, int D>
+__device__ __forceinline__ void split_kstep_stream(WRing<D>& r, const h8* __restrict__ Wlane, int kk,
+                                                   const BFrag (&B)[KT], f32x4 (&Y)[NTO][KT]) {
+#pragma unroll
+  for (int to = 0; to < NTO; ++to) {
+    const int q = kk * NTO + to;
+    if (q + D < NKK * NTO) wring_load<NKK, NTO, D>(r, Wlane, q + D);
+#pragma unroll
+    for (int c = 0; c < KT; ++c) Y[to][c] = mfma_split(r.hi[q % (D + 1)], r.lo[q % (D + 1)], B[c], Y[to][c]);
+  }
+}
+
+template <int KT, int NKK, int NTO, int D>
+__device__ __forceinline__ void split_gemm_stream(const h8* __restrict__ Wlane, const BFrag (&B)[NKK][KT],
+                                                  f32x4 (&Y)[NTO][KT]) {
+  WRing<D> r;
+  wring_prologue<NKK, NTO, D>(r, Wlane);
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) {
+    split_kstep_stream<KT, NKK, NTO, D>(r, Wlane, kk, B[kk], Y);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // fp32 register tile (NT_ feature tiles) -> NT_/2 k-steps of B fragments, optionally through GELU
 template <int NT_, int KT, bool GELU>
 __device__ __forceinline__ void tile_to_bfrag(const f32x4 (&V)[NT_][KT], BFrag (&B)[NT_ / 2][KT]) {

@@ -228,7 +228,7 @@ __global__ void k_pack_linear(const float* __restrict__ W, int out_f, int in_f, 
 
 // split-f16 packing (see mpnn_common.h): packed[to][kk][part][lane] is an h8 whose element j is the hi (part 0)
 // or lo (part 1) half of W[16 to + (lane&15)][col0 + 16 (2 kk + (j>>2)) + 4 (lane>>4) + (j&3)]
-__global__ void k_pack_linear_split(const float* __restrict__ W, int out_f, int in_f, int ld, int col0,
+__global__ void k_pack_linear_split(const float* __restrict__ W, int out_f, int in_f, int ld, int col0, int rot,
                                     h8* __restrict__ packed, int nto, int nkk) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one (to, kk, lane)
   if (idx >= nto * nkk * 64) return;
@@ -238,7 +238,8 @@ __global__ void k_pack_linear_split(const float* __restrict__ W, int out_f, int 
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int col = 16 * (2 * kk + (j >> 2)) + 4 * (lane >> 4) + (j & 3);
-    const float w = (row < out_f && col < in_f) ? W[(size_t)row * ld + col0 + col] : 0.f;
+    // rot rotates the input features: packed column `col` is source column (col + rot) mod in_f
+    const float w = (row < out_f && col < in_f) ? W[(size_t)row * ld + col0 + (col + rot) % in_f] : 0.f;
     const _Float16 h = (_Float16)w;
     hi[j] = h;
     lo[j] = (_Float16)(w - (float)h);
@@ -257,28 +258,32 @@ __global__ void k_pos_table(const float* __restrict__ W, const float* __restrict
 }
 
 // ---------------------------------------------------------------------------
-// edge features: one wavefront per residue, KT column tiles of 16 neighbours.
-//   B operand generated on the fly:  k-tile 0 = positional table row (16 values),
-//   k-tile 1 + a1*A + a2 = 16 RBFs of |atom_a1(i) - atom_a2(j)|   (:344-347 product order)
+// edge features: one wavefront per residue, KT column tiles of 16 neighbours, split-f16 MFMA.
+//   B operand generated on the fly, one k-step = two 16-feature tiles.  Tile order (the packed
+//   edge_embedding weight is rotated by 16 columns to match): tiles 0 .. A*A-1 = the 16 RBFs of
+//   |atom_a1(i) - atom_a2(j)| in itertools.product order (:344-347), tile A*A = positional table row
+//   (:349-356), then zero padding to an even tile count.
 //   E   = LayerNorm(W_emb . feat)            (:357-359)
 //   h_E = W_e . E + b_e                      (:464)
-// A operands (packed W_emb, W_e) stream from L2; outputs: hE in fragment layout and,
-// optionally, E in the reference's natural [N,K,128] layout.
+// Both weights stream from L2 as A fragments; outputs: hE in fragment layout and, optionally, E in the
+// reference's natural [N,K,128] layout.
 // ---------------------------------------------------------------------------
 template <int KT, int A>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, const long long* __restrict__ residue_idx,
                 const long long* __restrict__ chain_labels, const float* __restrict__ pos_table,
-                const float* __restrict__ rbf_mu, const f32x4* __restrict__ Wemb, const float* __restrict__ ln_w,
-                const float* __restrict__ ln_b, const f32x4* __restrict__ We, const float* __restrict__ be, int N,
+                const float* __restrict__ rbf_mu, const h8* __restrict__ Wemb, const float* __restrict__ ln_w,
+                const float* __restrict__ ln_b, const h8* __restrict__ We, const float* __restrict__ be, int N,
                 int L, int K, float* __restrict__ E_nat, float* __restrict__ hE) {
-  constexpr int NTI = 1 + A * A;
+  constexpr int NT_IN = A * A + 1;            // feature tiles: pairs, then positional
+  constexpr int NKK_IN = (NT_IN + 1) / 2;     // k-steps of 32 features
+  constexpr int D = 3;
   const int lane = threadIdx.x & 63;
   const int node = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (node >= N) return;
   const int g = lane >> 4, col = lane & 15;
   const int b = node / L;
-  const int Kp = KT * 16;
+  constexpr int Kp = KT * 16;
 
   int jn[KT];  // neighbour node (global index)
 #pragma unroll
@@ -290,10 +295,28 @@ k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, 
 #pragma unroll
     for (int c = 0; c < KT; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- k-tile 0: positional encodings
-  {
+  float mu[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) mu[r] = rbf_mu[4 * g + r];
+  const f32x4* atom_i = reinterpret_cast<const f32x4*>(atoms + (size_t)node * 24);
+
+  // 16 RBFs (this lane: 4 of them) of atom pair p for each column tile
+  auto rbf_tile = [&](int pair, f32x4 (&x)[KT]) {
+    const f32x4 Ai = atom_i[pair / A];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      const f32x4 Bj = reinterpret_cast<const f32x4*>(atoms + (size_t)jn[c] * 24)[pair % A];
+      const float dx = Ai.x - Bj.x, dy = Ai.y - Bj.y, dz = Ai.z - Bj.z;
+      const float d = sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float z = (d - mu[r]) * 0.96089792702915982f;  // (1 / 1.25) sqrt(log2 e)
+        x[c][r] = __builtin_amdgcn_exp2f(-(z * z));           // exp(-((d - mu) / 1.25)^2)
+      }
+    }
+  };
+  auto pos_tile = [&](f32x4 (&x)[KT]) {
     const long long ri = residue_idx[node], ci = chain_labels[node];
-    f32x4 x[KT];
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
       const long long off = ri - residue_idx[jn[c]];
@@ -303,49 +326,32 @@ k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, 
       if (!same) d = 65;
       x[c] = *reinterpret_cast<const f32x4*>(pos_table + d * 16 + 4 * g);
     }
+  };
+  auto feature_tile = [&](int tt, f32x4 (&x)[KT]) {
+    if (tt < A * A) {
+      rbf_tile(tt, x);
+    } else if (tt == A * A) {
+      pos_tile(x);
+    } else {
 #pragma unroll
-    for (int to = 0; to < MPNN_NT; ++to) {
-      const f32x4 a = Wemb[(to * NTI + 0) * 64 + lane];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < KT; ++c) acc[to][c] = mfma4(a[r], x[c][r], acc[to][c]);
+      for (int c = 0; c < KT; ++c) x[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  }
-  // ---- k-tiles 1..A*A: RBFs
-  float mu[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) mu[r] = rbf_mu[4 * g + r];
-  f32x4 Bj[A][KT];
-#pragma unroll
-  for (int a2 = 0; a2 < A; ++a2)
-#pragma unroll
-    for (int c = 0; c < KT; ++c) Bj[a2][c] = reinterpret_cast<const f32x4*>(atoms + (size_t)jn[c] * 24)[a2];
+  };
 
-  for (int a1 = 0; a1 < A; ++a1) {
-    const f32x4 Ai = reinterpret_cast<const f32x4*>(atoms + (size_t)node * 24)[a1];
+  {
+    const h8* Wl = Wemb + lane;
+    WRing<D> ring;
+    wring_prologue<NKK_IN, MPNN_NT, D>(ring, Wl);
 #pragma unroll
-    for (int a2 = 0; a2 < A; ++a2) {
-      const int ti = 1 + a1 * A + a2;
-      f32x4 x[KT];
+    for (int kk = 0; kk < NKK_IN; ++kk) {
+      f32x4 x0[KT], x1[KT];
+      feature_tile(2 * kk, x0);
+      feature_tile(2 * kk + 1, x1);
+      BFrag bf[KT];
 #pragma unroll
-      for (int c = 0; c < KT; ++c) {
-        const float dx = Ai.x - Bj[a2][c].x, dy = Ai.y - Bj[a2][c].y, dz = Ai.z - Bj[a2][c].z;
-        const float d = sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float z = (d - mu[r]) * 0.96089792702915982f;  // (1 / 1.25) sqrt(log2 e)
-          x[c][r] = __builtin_amdgcn_exp2f(-(z * z));           // exp(-((d - mu) / 1.25)^2)
-        }
-      }
-#pragma unroll
-      for (int to = 0; to < MPNN_NT; ++to) {
-        const f32x4 a = Wemb[(to * NTI + ti) * 64 + lane];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c < KT; ++c) acc[to][c] = mfma4(a[r], x[c][r], acc[to][c]);
-      }
+      for (int c = 0; c < KT; ++c) split_pair(x0[c], x1[c], bf[c]);
+      split_kstep_stream<KT, NKK_IN, MPNN_NT, D>(ring, Wl, kk, bf, acc);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // ---- LayerNorm over features (norm_edges)
@@ -362,25 +368,20 @@ k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, 
     }
   }
   // ---- h_E = W_e E + b
+  BFrag eb[MPNN_NT / 2][KT];
+  tile_to_bfrag<MPNN_NT, KT, false>(acc, eb);
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(be + 16 * t + 4 * g);
+#pragma unroll
+    for (int c = 0; c < KT; ++c) acc[t][c] = bb;
+  }
+  split_gemm_stream<KT, MPNN_NT / 2, MPNN_NT, D>(We + lane, eb, acc);
   f32x4* out = reinterpret_cast<f32x4*>(hE) + (size_t)node * (MPNN_NT * KT * 64);
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    f32x4 y[4][KT];
+  for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(be + 16 * (4 * half + t) + 4 * g);
-#pragma unroll
-      for (int c = 0; c < KT; ++c) y[t][c] = bb;
-    }
-    if (half == 0)
-      tile_gemm<KT, MPNN_NT, 0, 4>(We, lane, acc, y);
-    else
-      tile_gemm<KT, MPNN_NT, 4, 8>(We, lane, acc, y);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int c = 0; c < KT; ++c) out[((4 * half + t) * KT + c) * 64 + lane] = y[t][c];
-  }
+    for (int c = 0; c < KT; ++c) out[(t * KT + c) * 64 + lane] = acc[t][c];
 }
 
 // ---------------------------------------------------------------------------
@@ -486,12 +487,13 @@ extern "C" int mpnn_pack_linear(const float* W, int out_f, int in_f, int ld, int
   MPNN_LAUNCH_CHECK();
 }
 
-extern "C" int mpnn_pack_linear_split(const float* W, int out_f, int in_f, int ld, int col0, void* packed,
+extern "C" int mpnn_pack_linear_split(const float* W, int out_f, int in_f, int ld, int col0, int rot, void* packed,
                                       void* stream) {
-  MPNN_CHECK_ARG(W && packed && out_f > 0 && in_f > 0 && ld >= col0 + in_f, "mpnn_pack_linear_split: bad arguments");
+  MPNN_CHECK_ARG(W && packed && out_f > 0 && in_f > 0 && ld >= col0 + in_f && rot >= 0 && rot < in_f,
+                 "mpnn_pack_linear_split: bad arguments");
   const int nto = (out_f + 15) / 16, nkk = (in_f + 31) / 32;
   hipLaunchKernelGGL(k_pack_linear_split, dim3(ceil_div((long long)nto * nkk * 64, 256)), dim3(256), 0,
-                     (hipStream_t)stream, W, out_f, in_f, ld, col0, (h8*)packed, nto, nkk);
+                     (hipStream_t)stream, W, out_f, in_f, ld, col0, rot, (h8*)packed, nto, nkk);
   MPNN_LAUNCH_CHECK();
 }
 
@@ -510,10 +512,10 @@ static int launch_edge_features(int A, const float* atoms, const int* E_idx, con
   dim3 grid(ceil_div(N, 4)), block(256);
   if (A == 5)
     hipLaunchKernelGGL((k_edge_features<KT, 5>), grid, block, 0, s, atoms, E_idx, ridx, chain, pos_table, rbf_mu,
-                       (const f32x4*)Wemb, ln_w, ln_b, (const f32x4*)We, be, N, L, K, E_nat, hE);
+                       (const h8*)Wemb, ln_w, ln_b, (const h8*)We, be, N, L, K, E_nat, hE);
   else
     hipLaunchKernelGGL((k_edge_features<KT, 6>), grid, block, 0, s, atoms, E_idx, ridx, chain, pos_table, rbf_mu,
-                       (const f32x4*)Wemb, ln_w, ln_b, (const f32x4*)We, be, N, L, K, E_nat, hE);
+                       (const h8*)Wemb, ln_w, ln_b, (const h8*)We, be, N, L, K, E_nat, hE);
   MPNN_LAUNCH_CHECK();
 }
 

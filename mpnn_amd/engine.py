@@ -58,7 +58,7 @@ class PackedWeights:
             call("mpnn_pack_linear", ptr(W), out_f, ncols, ld, col0, ptr(out), st)
             return out
 
-        def pack_split(W, col0=0, ncols=None):
+        def pack_split(W, col0=0, ncols=None, rot=0):
             """f16 hi/lo split packing for the matrix-pipe kernels: [out/16][in/32][2][64] x 16 B."""
             W = _f32(W)
             self._keep.append(W)
@@ -66,7 +66,7 @@ class PackedWeights:
             ncols = ld - col0 if ncols is None else ncols
             nto, nkk = (out_f + 15) // 16, (ncols + 31) // 32
             out = torch.empty(nto * nkk * 2 * 64 * 4, device=dev, dtype=torch.float32)  # 16 B per lane
-            call("mpnn_pack_linear_split", ptr(W), out_f, ncols, ld, col0, ptr(out), st)
+            call("mpnn_pack_linear_split", ptr(W), out_f, ncols, ld, col0, rot, ptr(out), st)
             return out
 
         def vec(b):
@@ -92,9 +92,9 @@ class PackedWeights:
         self._keep += [Wl, bl]
         call("mpnn_pos_table", ptr(Wl), ptr(bl), 66, 16, ptr(self.pos_table), st)
         self.rbf_mu = torch.linspace(2.0, 22.0, 16, device=dev, dtype=torch.float32)
-        self.Wemb = pack(f.edge_embedding.weight)
+        self.Wemb = pack_split(f.edge_embedding.weight, rot=16)  # feature order: RBF blocks, then positional
         self.ln_e_w, self.ln_e_b = vec(f.norm_edges.weight), vec(f.norm_edges.bias)
-        self.We, self.be = pack(model.W_e.weight), vec(model.W_e.bias)
+        self.We, self.be = pack_split(model.W_e.weight), vec(model.W_e.bias)
 
         enc, dec = list(model.encoder_layers), list(model.decoder_layers)
         self.enc, self.dec = [], []
@@ -259,11 +259,11 @@ class _FeaturePack:
         call("mpnn_pos_table", ptr(Wl), ptr(bl), 66, 16, ptr(c.pos_table), st)
         c.rbf_mu = torch.linspace(2.0, 22.0, 16, device=dev, dtype=torch.float32)
         W = _f32(fm.edge_embedding.weight)
-        nti = (W.shape[1] + 15) // 16
-        c.Wemb = torch.empty(8 * nti * 256, device=dev, dtype=torch.float32)
-        call("mpnn_pack_linear", ptr(W), H, W.shape[1], W.shape[1], 0, ptr(c.Wemb), st)
+        nkk = (W.shape[1] + 31) // 32
+        c.Wemb = torch.empty(8 * nkk * 512, device=dev, dtype=torch.float32)
+        call("mpnn_pack_linear_split", ptr(W), H, W.shape[1], W.shape[1], 0, 16, ptr(c.Wemb), st)
         c.ln_e_w, c.ln_e_b = _f32(fm.norm_edges.weight), _f32(fm.norm_edges.bias)
-        c.We = torch.zeros(8 * 8 * 256, device=dev, dtype=torch.float32)
+        c.We = torch.zeros(8 * 4 * 512, device=dev, dtype=torch.float32)
         c.be = torch.zeros(H, device=dev, dtype=torch.float32)
         c._keep = (Wl, bl, W)
         fm._packed = c
@@ -443,7 +443,7 @@ def enc_layer_standalone(layer, h_V, h_E, E_idx, mask_V=None, mask_attend=None):
             out_f, ld = W.shape
             ncols = ld - col0 if ncols is None else ncols
             out = torch.empty(((out_f + 15) // 16) * ((ncols + 31) // 32) * 512, device=dev, dtype=torch.float32)
-            call("mpnn_pack_linear_split", ptr(W), out_f, ncols, ld, col0, ptr(out), st)
+            call("mpnn_pack_linear_split", ptr(W), out_f, ncols, ld, col0, 0, ptr(out), st)
             return out
         c = dict(key=key, g1=(Wp, bp, 2), g2=(Wp2, bp2, 2), W1b=pack_split(layer.W1.weight, H, H),
                  W2=pack_split(layer.W2.weight),
