@@ -4,29 +4,69 @@
 #include "mpnn_common.h"
 
 // ---------------------------------------------------------------------------
-// node update + projections: one wavefront per 16 nodes, all weights streamed from L2.
+// node update + projections: one wavefront per 16 nodes, 4 waves (64 nodes) per workgroup, split-f16 MFMA.
 //   dh  = (W3 gsum + cnt b3) / scale                               (:78-81 with W3 hoisted)
 //   x   = LN1(h + dh);  y = LN2(x + W_out gelu(W_in x + b_in) + b_out);  h' = mask * y   (:82-88)
 //   PQ  = Wproj h' + bproj      (nproj blocks of 128 outputs: the next kernels' P/Q terms)
 // do_update = 0 skips the update and only projects h.
+// The node level has little parallelism (N / 16 wave tiles) and ~0.8 MB of weights per layer, so the kernel
+// is a weight-streaming problem: the 9 + nproj packed 128x128 matrices (64 KiB each: W3, then W_in / W_out in
+// four hidden-unit quarters, then the projections) flow through a two-slot LDS ring by LDS-DMA
+// (global_load_lds), fetched once per workgroup and one matrix ahead of the MFMAs that consume them.
 // ---------------------------------------------------------------------------
+constexpr int NKK = MPNN_NT / 2;
+constexpr int WSPLIT = MPNN_NT * NKK * 2 * 64;  // h8 elements of one packed 128x128 split matrix
+
+__device__ __forceinline__ void stage_matrix(const h8* __restrict__ g, h8* l) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < WSPLIT / 256; ++i) {
+    const int chunk = i * 4 + wave;  // 1 KiB per wave-instruction, LDS image is lane-linear
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + chunk * 64 + lane),
+                                     (__attribute__((address_space(3))) void*)(l + chunk * 64), 16, 0, 0);
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, const float* __restrict__ cnt,
-              float cnt_const, const float* __restrict__ mask, const f32x4* __restrict__ W3,
+              float cnt_const, const float* __restrict__ mask, const h8* __restrict__ W3,
               const float* __restrict__ b3, const float* __restrict__ ln1w, const float* __restrict__ ln1b,
-              const f32x4* __restrict__ Win, const float* __restrict__ bin, const f32x4* __restrict__ Wout,
+              const h8* __restrict__ Win, const float* __restrict__ bin, const h8* __restrict__ Wout,
               const float* __restrict__ bout, const float* __restrict__ ln2w, const float* __restrict__ ln2b,
-              float inv_scale, int do_update, const f32x4* __restrict__ Wproj, const float* __restrict__ bproj,
+              float inv_scale, int do_update, const h8* __restrict__ Wproj, const float* __restrict__ bproj,
               int nproj, const float* __restrict__ add_table, int ld_table, int off_table,
               const long long* __restrict__ add_idx, int add_block, int N, float* __restrict__ hV_out,
               float* __restrict__ PQ) {
+  __shared__ h8 lds[2 * WSPLIT];
   const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (tile * 16 >= N) return;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int g = lane >> 4, col = lane & 15;
   const int node = tile * 16 + col;
-  const bool live = node < N;
+  const bool live = node < N;       // no early exit: every wave takes part in the staging barriers
   const int nd = live ? node : N - 1;
+
+  const int nmat = (do_update ? 9 : 0) + nproj;
+  auto matrix = [&](int k) -> const h8* {
+    if (do_update) {
+      if (k == 0) return W3;
+      if (k < 9) return (((k - 1) & 1) ? Wout : Win) + (size_t)((k - 1) >> 1) * WSPLIT;
+      k -= 9;
+    }
+    return Wproj + (size_t)k * WSPLIT;
+  };
+  int k = 0;
+  if (nmat > 0) stage_matrix(matrix(0), lds);
+  // fetch matrix k+1 into the other slot (every wave passed the barrier that ended matrix k-1's use of it)
+  auto prefetch = [&]() {
+    if (k + 1 < nmat) stage_matrix(matrix(k + 1), lds + ((k + 1) & 1) * WSPLIT);
+  };
+  auto retire = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ++k;
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
   f32x4 h[MPNN_NT][1];
 #pragma unroll
@@ -41,20 +81,33 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
       gs[t][0] = *reinterpret_cast<const f32x4*>(gsum + (size_t)nd * MPNN_H + 16 * t + 4 * g);
       dh[t][0] = *reinterpret_cast<const f32x4*>(b3 + 16 * t + 4 * g) * cn;
     }
-    tile_gemm<1, MPNN_NT, 0, 8>(W3, lane, gs, dh);
+    BFrag xb[NKK][1];
+    tile_to_bfrag<MPNN_NT, 1, false>(gs, xb);
+    prefetch();
+    split_gemm<1, NKK, 0, MPNN_NT>(lds + (k & 1) * WSPLIT, lane, xb, dh);
+    retire();
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) h[t][0] = h[t][0] + dh[t][0] * inv_scale;
     tile_layernorm<1>(h, ln1w, ln1b, lane);
-    // FFN
-    f32x4 hid[32][1];
-#pragma unroll
-    for (int t = 0; t < 32; ++t) hid[t][0] = *reinterpret_cast<const f32x4*>(bin + 16 * t + 4 * g);
-    tile_gemm<1, MPNN_NT, 0, 32>(Win, lane, h, hid);
-    tile_gelu<32, 1>(hid);
+    tile_to_bfrag<MPNN_NT, 1, false>(h, xb);
     f32x4 o[MPNN_NT][1];
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) o[t][0] = h[t][0] + *reinterpret_cast<const f32x4*>(bout + 16 * t + 4 * g);
-    tile_gemm<1, 32, 0, 8>(Wout, lane, hid, o);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // FFN hidden units in quarters of 128
+      f32x4 hid[MPNN_NT][1];
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+        hid[t][0] = *reinterpret_cast<const f32x4*>(bin + 128 * q + 16 * t + 4 * g);
+      prefetch();
+      split_gemm<1, NKK, 0, MPNN_NT>(lds + (k & 1) * WSPLIT, lane, xb, hid);
+      retire();
+      BFrag hb[NKK][1];
+      tile_to_bfrag<MPNN_NT, 1, true>(hid, hb);
+      prefetch();
+      split_gemm<1, NKK, 0, MPNN_NT>(lds + (k & 1) * WSPLIT, lane, hb, o);
+      retire();
+    }
     tile_layernorm<1>(o, ln2w, ln2b, lane);
     const float mk = mask[nd];
 #pragma unroll
@@ -63,13 +116,17 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
       if (live) *reinterpret_cast<f32x4*>(hV_out + (size_t)node * MPNN_H + 16 * t + 4 * g) = h[t][0];
     }
   }
+  BFrag pb[NKK][1];
+  tile_to_bfrag<MPNN_NT, 1, false>(h, pb);
   const int ld = nproj * MPNN_H;
   for (int p = 0; p < nproj; ++p) {
     f32x4 y[MPNN_NT][1];
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) y[t][0] = *reinterpret_cast<const f32x4*>(bproj + p * MPNN_H + 16 * t + 4 * g);
-    tile_gemm<1, MPNN_NT, 0, 8>(Wproj + (size_t)p * 4096, lane, h, y);
-    if (add_table && p == add_block) {  // decoder: fold the sequence term W1c W_s[S_n] into the PV block
+    prefetch();
+    split_gemm<1, NKK, 0, MPNN_NT>(lds + (k & 1) * WSPLIT, lane, pb, y);
+    retire();
+    if (add_table && p == add_block) {  // decoder: fold the sequence term W1c W_s[S_n] into the A block
       const float* tr = add_table + (size_t)add_idx[nd] * ld_table + off_table + 4 * g;
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t) y[t][0] += *reinterpret_cast<const f32x4*>(tr + 16 * t);
@@ -181,9 +238,9 @@ extern "C" int mpnn_node_update(const float* hV_in, const float* gsum, const flo
     MPNN_CHECK_ARG(add_idx && add_block >= 0 && add_block < nproj && ((ld_table | off_table) & 3) == 0,
                    "mpnn_node_update: bad table-add arguments");
   hipLaunchKernelGGL(k_node_update, dim3(ceil_div(n_nodes, 64)), dim3(256), 0, (hipStream_t)stream, hV_in, gsum, cnt,
-                     cnt_const, mask, (const f32x4*)W3_packed, b3, ln1_w, ln1_b, (const f32x4*)Win_packed, b_in,
-                     (const f32x4*)Wout_packed, b_out, ln2_w, ln2_b, 1.0f / scale, do_update,
-                     (const f32x4*)Wproj_packed, bproj, nproj, add_table, ld_table, off_table,
+                     cnt_const, mask, (const h8*)W3_packed, b3, ln1_w, ln1_b, (const h8*)Win_packed, b_in,
+                     (const h8*)Wout_packed, b_out, ln2_w, ln2_b, 1.0f / scale, do_update,
+                     (const h8*)Wproj_packed, bproj, nproj, add_table, ld_table, off_table,
                      (const long long*)add_idx, add_block, n_nodes, hV_out, PQ);
   MPNN_LAUNCH_CHECK();
 }

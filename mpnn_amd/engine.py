@@ -58,14 +58,15 @@ class PackedWeights:
             call("mpnn_pack_linear", ptr(W), out_f, ncols, ld, col0, ptr(out), st)
             return out
 
-        def pack_split(W, col0=0, ncols=None, rot=0):
+        def pack_split(W, col0=0, ncols=None, rot=0, out=None):
             """f16 hi/lo split packing for the matrix-pipe kernels: [out/16][in/32][2][64] x 16 B."""
             W = _f32(W)
             self._keep.append(W)
             out_f, ld = W.shape
             ncols = ld - col0 if ncols is None else ncols
             nto, nkk = (out_f + 15) // 16, (ncols + 31) // 32
-            out = torch.empty(nto * nkk * 2 * 64 * 4, device=dev, dtype=torch.float32)  # 16 B per lane
+            if out is None:
+                out = torch.empty(nto * nkk * 2 * 64 * 4, device=dev, dtype=torch.float32)  # 16 B per lane
             call("mpnn_pack_linear_split", ptr(W), out_f, ncols, ld, col0, rot, ptr(out), st)
             return out
 
@@ -73,14 +74,14 @@ class PackedWeights:
             return _f32(b)
 
         def proj_group(blocks):
-            """blocks: list of (W, col0, bias|None) -> (packed [n][8][8][64][4], bias [n*128])."""
+            """blocks: list of (W, col0, bias|None) -> (n split-packed 128x128 matrices, bias [n*128])."""
             n = len(blocks)
             if n == 0:
                 return None, None, 0
-            Wp = torch.empty(n * 4096 * 4, device=dev, dtype=torch.float32)
+            Wp = torch.empty(n * 16384, device=dev, dtype=torch.float32)  # n split-packed 128x128 (64 KiB each)
             bp = torch.zeros(n * H, device=dev, dtype=torch.float32)
             for i, (W, col0, b) in enumerate(blocks):
-                pack(W, col0, H, out=Wp[i * 16384:(i + 1) * 16384])
+                pack_split(W, col0, H, out=Wp[i * 16384:(i + 1) * 16384])
                 if b is not None:
                     bp[i * H:(i + 1) * H] = _f32(b)
             return Wp, bp, n
@@ -100,21 +101,23 @@ class PackedWeights:
         self.enc, self.dec = [], []
         for lyr in enc:
             d = dict(W1b=pack_split(lyr.W1.weight, H, H), W2=pack_split(lyr.W2.weight), b2=vec(lyr.W2.bias),
-                     W3=pack(lyr.W3.weight), b3=vec(lyr.W3.bias),
+                     W3=pack_split(lyr.W3.weight), b3=vec(lyr.W3.bias),
                      W11b=pack_split(lyr.W11.weight, H, H), W12=pack_split(lyr.W12.weight), b12=vec(lyr.W12.bias),
                      W13=pack_split(lyr.W13.weight), b13=vec(lyr.W13.bias),
                      ln1w=vec(lyr.norm1.weight), ln1b=vec(lyr.norm1.bias), ln2w=vec(lyr.norm2.weight),
                      ln2b=vec(lyr.norm2.bias), ln3w=vec(lyr.norm3.weight), ln3b=vec(lyr.norm3.bias),
-                     Win=pack(lyr.dense.W_in.weight), bin=vec(lyr.dense.W_in.bias),
-                     Wout=pack(lyr.dense.W_out.weight), bout=vec(lyr.dense.W_out.bias), scale=float(lyr.scale))
+                     Win=pack_split(lyr.dense.W_in.weight), bin=vec(lyr.dense.W_in.bias),
+                     Wout=torch.cat([pack_split(lyr.dense.W_out.weight, H * q, H) for q in range(4)]),
+                     bout=vec(lyr.dense.W_out.bias), scale=float(lyr.scale))
             self.enc.append(d)
         for lyr in dec:
             d = dict(W1b=pack_split(lyr.W1.weight, H, H), W2=pack_split(lyr.W2.weight), b2=vec(lyr.W2.bias),
-                     W3=pack(lyr.W3.weight), b3=vec(lyr.W3.bias),
+                     W3=pack_split(lyr.W3.weight), b3=vec(lyr.W3.bias),
                      ln1w=vec(lyr.norm1.weight), ln1b=vec(lyr.norm1.bias), ln2w=vec(lyr.norm2.weight),
                      ln2b=vec(lyr.norm2.bias),
-                     Win=pack(lyr.dense.W_in.weight), bin=vec(lyr.dense.W_in.bias),
-                     Wout=pack(lyr.dense.W_out.weight), bout=vec(lyr.dense.W_out.bias), scale=float(lyr.scale))
+                     Win=pack_split(lyr.dense.W_in.weight), bin=vec(lyr.dense.W_in.bias),
+                     Wout=torch.cat([pack_split(lyr.dense.W_out.weight, H * q, H) for q in range(4)]),
+                     bout=vec(lyr.dense.W_out.bias), scale=float(lyr.scale))
             self.dec.append(d)
 
         # projection groups: what the NEXT edge kernel needs from the node features
@@ -427,17 +430,6 @@ def enc_layer_standalone(layer, h_V, h_E, E_idx, mask_V=None, mask_attend=None):
     key = tuple((p.data_ptr(), p._version) for p in layer.parameters())
     c = getattr(layer, "_packed", None)
     if c is None or c["key"] != key:
-        def pack(W, col0=0, ncols=None):
-            W = _f32(W)
-            out_f, ld = W.shape
-            ncols = ld - col0 if ncols is None else ncols
-            out = torch.empty(((out_f + 15) // 16) * ((ncols + 15) // 16) * 256, device=dev, dtype=torch.float32)
-            call("mpnn_pack_linear", ptr(W), out_f, ncols, ld, col0, ptr(out), st)
-            return out
-        Wp = torch.cat([pack(layer.W1.weight, 0, H), pack(layer.W1.weight, 2 * H, H)])
-        bp = torch.cat([_f32(layer.W1.bias), torch.zeros(H, device=dev)])
-        Wp2 = torch.cat([pack(layer.W11.weight, 0, H), pack(layer.W11.weight, 2 * H, H)])
-        bp2 = torch.cat([_f32(layer.W11.bias), torch.zeros(H, device=dev)])
         def pack_split(W, col0=0, ncols=None):
             W = _f32(W)
             out_f, ld = W.shape
@@ -445,14 +437,19 @@ def enc_layer_standalone(layer, h_V, h_E, E_idx, mask_V=None, mask_attend=None):
             out = torch.empty(((out_f + 15) // 16) * ((ncols + 31) // 32) * 512, device=dev, dtype=torch.float32)
             call("mpnn_pack_linear_split", ptr(W), out_f, ncols, ld, col0, 0, ptr(out), st)
             return out
+        Wp = torch.cat([pack_split(layer.W1.weight, 0, H), pack_split(layer.W1.weight, 2 * H, H)])
+        bp = torch.cat([_f32(layer.W1.bias), torch.zeros(H, device=dev)])
+        Wp2 = torch.cat([pack_split(layer.W11.weight, 0, H), pack_split(layer.W11.weight, 2 * H, H)])
+        bp2 = torch.cat([_f32(layer.W11.bias), torch.zeros(H, device=dev)])
         c = dict(key=key, g1=(Wp, bp, 2), g2=(Wp2, bp2, 2), W1b=pack_split(layer.W1.weight, H, H),
                  W2=pack_split(layer.W2.weight),
-                 b2=_f32(layer.W2.bias), W3=pack(layer.W3.weight), b3=_f32(layer.W3.bias),
+                 b2=_f32(layer.W2.bias), W3=pack_split(layer.W3.weight), b3=_f32(layer.W3.bias),
                  W11b=pack_split(layer.W11.weight, H, H), W12=pack_split(layer.W12.weight), b12=_f32(layer.W12.bias),
                  W13=pack_split(layer.W13.weight), b13=_f32(layer.W13.bias), ln1w=_f32(layer.norm1.weight),
                  ln1b=_f32(layer.norm1.bias), ln2w=_f32(layer.norm2.weight), ln2b=_f32(layer.norm2.bias),
-                 ln3w=_f32(layer.norm3.weight), ln3b=_f32(layer.norm3.bias), Win=pack(layer.dense.W_in.weight),
-                 bin=_f32(layer.dense.W_in.bias), Wout=pack(layer.dense.W_out.weight),
+                 ln3w=_f32(layer.norm3.weight), ln3b=_f32(layer.norm3.bias), Win=pack_split(layer.dense.W_in.weight),
+                 bin=_f32(layer.dense.W_in.bias),
+                 Wout=torch.cat([pack_split(layer.dense.W_out.weight, H * q, H) for q in range(4)]),
                  bout=_f32(layer.dense.W_out.bias), scale=float(layer.scale))
         layer._packed = c
     hV = _f32(h_V).view(N, H)
