@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  (must be imported first: the library binds to the HIP runtime torch loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpnn_hip.so")
+LIB_PATH = os.environ.get("MPNN_HIP_LIB") or os.path.join(_HERE, "libmpnn_hip.so")  # override: kernel A/B builds
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int

@@ -48,11 +48,14 @@ __device__ __forceinline__ float gelu(float x) {
   p *= t;
   const float zs = z * 1.20112240878644977f;          // sqrt(log2 e): exp(-z^2) = exp2(-(zs^2))
   const float e = __builtin_amdgcn_exp2f(-(zs * zs));
-  const float r = (0.5f * x) * (p * e);               // 0.5 x erfc(|z|)
-  return x > 0.f ? x - r : r;                         // x Phi(x) without the 1 - erf cancellation for x < 0
+  const float r = (0.5f * fabsf(x)) * (p * e);         // 0.5 |x| erfc(|z|)  >= 0
+  return fmaxf(x, 0.f) - r;                           // x Phi(x) = relu(x) - 0.5 |x| erfc(|x| / sqrt 2)
 }
 
 __device__ __forceinline__ f32x4 gelu4(f32x4 v) {
+#ifdef MPNN_ABL_NOGELU  // timing-only ablation build: never shipped
+  return v;
+#endif
   f32x4 o;
   o.x = gelu(v.x); o.y = gelu(v.y); o.z = gelu(v.z); o.w = gelu(v.w);
   return o;
@@ -76,12 +79,20 @@ __device__ __forceinline__ float quarter_sum(float v) {
   return v;
 }
 
-// sum over the 16 columns of a quarter (lanes with the same lane>>4)
+// sum over the 16 columns of a quarter (lanes with the same lane>>4): DPP row rotations, every lane gets the sum
+template <int N_>
+__device__ __forceinline__ float row_ror_add(float v) {
+  const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N_, 0xf, 0xf, false);  // row_ror:N_
+  return v + __int_as_float(r);
+}
 __device__ __forceinline__ float column_sum(float v) {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
+#ifdef MPNN_ABL_NOREDUCE
+  return v;
+#endif
+  v = row_ror_add<8>(v);
+  v = row_ror_add<4>(v);
+  v = row_ror_add<2>(v);
+  v = row_ror_add<1>(v);
   return v;
 }
 
@@ -124,6 +135,14 @@ __device__ __forceinline__ void tile_gemm(WPtr Wp, int lane, const f32x4 (&X)[NT
 // ---------------------------------------------------------------------------
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
+#ifdef MPNN_ABL_NOMFMA  // timing-only ablation: operands stay live, the matrix pipe is never used
+__device__ __forceinline__ f32x4 abl_mfma(h8 a, h8 b, f32x4 c) {
+  asm volatile("" ::"v"(a), "v"(b));
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) abl_mfma(a, b, c)
+#endif
+
 struct BFrag {
   h8 hi, lo;
 };
@@ -153,8 +172,16 @@ __device__ __forceinline__ void split_kstep(WPtr Wp, int kk, int lane, const BFr
   for (int to = TO0; to < TO1; ++to) {
     const h8 a_hi = Wp[((to * NKK + kk) * 2 + 0) * 64 + lane];
     const h8 a_lo = Wp[((to * NKK + kk) * 2 + 1) * 64 + lane];
+    // the three partial products of one accumulator are issued KT MFMAs apart (no back-to-back dependence)
 #pragma unroll
-    for (int c = 0; c < KT; ++c) Y[to - TO0][c] = mfma_split(a_hi, a_lo, B[c], Y[to - TO0][c]);
+    for (int c = 0; c < KT; ++c)
+      Y[to - TO0][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, B[c].hi, Y[to - TO0][c], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < KT; ++c)
+      Y[to - TO0][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, B[c].lo, Y[to - TO0][c], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < KT; ++c)
+      Y[to - TO0][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, B[c].hi, Y[to - TO0][c], 0, 0, 0);
   }
 }
 
@@ -198,8 +225,13 @@ __device__ __forceinline__ void split_kstep_stream(WRing<D>& r, const h8* __rest
   for (int to = 0; to < NTO; ++to) {
     const int q = kk * NTO + to;
     if (q + D < NKK * NTO) wring_load<NKK, NTO, D>(r, Wlane, q + D);
+    const h8 a_hi = r.hi[q % (D + 1)], a_lo = r.lo[q % (D + 1)];
 #pragma unroll
-    for (int c = 0; c < KT; ++c) Y[to][c] = mfma_split(r.hi[q % (D + 1)], r.lo[q % (D + 1)], B[c], Y[to][c]);
+    for (int c = 0; c < KT; ++c) Y[to][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, B[c].hi, Y[to][c], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < KT; ++c) Y[to][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, B[c].lo, Y[to][c], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < KT; ++c) Y[to][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, B[c].hi, Y[to][c], 0, 0, 0);
   }
 }
 

@@ -25,6 +25,11 @@
 #ifndef MPNN_MSG_WAVES
 #define MPNN_MSG_WAVES 8
 #endif
+// 1: always use the tile-wise message kernel; 0: one-residue-per-wave kernel for K <= 48, tile-wise above
+// (measured equal at K = 48: 0.26 ms per launch at B32 x L512 either way)
+#ifndef MPNN_MSG_TILEWISE
+#define MPNN_MSG_TILEWISE 0
+#endif
 #ifndef MPNN_UPD_WAVES
 #define MPNN_UPD_WAVES 8
 #endif
@@ -39,6 +44,9 @@ __device__ __forceinline__ void lds_fill(h8* dst, const h8* __restrict__ src, in
 }
 
 __device__ __forceinline__ f32x4 row_tile(const float* row, int t) {
+#ifdef MPNN_ABL_NOROW  // timing-only ablation
+  return f32x4{0.1f, 0.2f, 0.3f, 0.4f};
+#endif
   return *reinterpret_cast<const f32x4*>(row + 16 * t);
 }
 
@@ -61,7 +69,12 @@ __device__ __forceinline__ void layer1_stream(const h8* Ws, const f32x4* __restr
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int c = 0; c < KT; ++c) xb[(kk + 1) & 1][u][c] = x[((2 * (kk + 1) + u) * KT + c) * 64];
+        for (int c = 0; c < KT; ++c)
+#ifdef MPNN_ABL_NOXLOAD
+          xb[(kk + 1) & 1][u][c] = f32x4{1.f, 2.f, 3.f, 4.f};
+#else
+          xb[(kk + 1) & 1][u][c] = x[((2 * (kk + 1) + u) * KT + c) * 64];
+#endif
     }
     BFrag b[KT];
 #pragma unroll
@@ -323,6 +336,110 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ PQ, int ldpq
   }
 }
 
+// ---------------------------------------------------------------------------
+// message kernel, tile-wise form: a wave walks its residue's column tiles (16 neighbours) one at a time.
+// Per-wave state shrinks from 2 x 96 to 2 x 32 accumulator registers, so 3-4 waves fit per SIMD and their
+// VALU (GELU, f16 splitting), MFMA and memory phases overlap; the price is that every weight fragment is read
+// from LDS once per column tile instead of once per residue (LDS ~30 % busy, the VALU stays the bound).
+// Works for any K (loop count = ceil(K / 16)).
+// ---------------------------------------------------------------------------
+#ifndef MPNN_MSGT_WAVES
+#define MPNN_MSGT_WAVES 12
+#endif
+
+template <bool DEC>
+__global__ void __launch_bounds__(MPNN_MSGT_WAVES * 64)
+k_message_tiles(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp, int offP,
+                const float* __restrict__ Abuf, int lda, int offA, const float* __restrict__ Bbuf, int ldb, int offB,
+                const int* __restrict__ rank, const int* __restrict__ E_idx, const float* __restrict__ mask,
+                const float* __restrict__ edge_mask, const h8* __restrict__ W1b, const h8* __restrict__ W2,
+                const float* __restrict__ b2, int N, int L, int K, int KT, float* __restrict__ gsum,
+                float* __restrict__ cnt) {
+  __shared__ h8 lds[2 * WSPLIT];
+  lds_fill(lds, W1b, WSPLIT);
+  lds_fill(lds + WSPLIT, W2, WSPLIT);
+  __syncthreads();
+  const h8* W1s = lds;
+  const h8* W2s = lds + WSPLIT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  const int Kp = KT * 16;
+  const int stride = gridDim.x * MPNN_MSGT_WAVES;
+
+  for (int node = blockIdx.x * MPNN_MSGT_WAVES + wave; node < N; node += stride) {
+    const int b = node / L;
+    const float mi = mask[node];
+    int ri = 0;
+    if (DEC) ri = rank[node];
+    const float* Pi = Pbuf + (size_t)node * ldp + offP + 4 * g;
+    f32x4 gacc[MPNN_NT][1];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) gacc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float wsum = 0.f;
+#pragma unroll 1
+    for (int c = 0; c < KT; ++c) {
+      LAUNDER(b2);
+      const int e = 16 * c + col;
+      const int jn = b * L + E_idx[(size_t)node * Kp + e];
+      float em = 1.0f;
+      if (edge_mask && e < K) em = edge_mask[(size_t)node * K + e];
+      const float* row;
+      float sc, w;
+      if (DEC) {
+        const bool before = ri > rank[jn];
+        row = before ? (Abuf + (size_t)jn * lda + offA + 4 * g) : (Bbuf + (size_t)jn * ldb + offB + 4 * g);
+        sc = mi * em;
+        w = e < K ? 1.0f : 0.0f;
+      } else {
+        row = Abuf + (size_t)jn * lda + offA + 4 * g;
+        sc = 1.0f;
+        w = e < K ? mi * mask[jn] * em : 0.0f;
+      }
+      wsum += w;
+      const f32x4* x = hE + ((size_t)node * MPNN_NT * KT + c) * 64 + lane;  // tile t of this column: x[t * KT * 64]
+      f32x4 xt[MPNN_NT];
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t) xt[t] = x[(size_t)t * KT * 64];
+      f32x4 h1[MPNN_NT][1];
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t) h1[t][0] = row_tile(row, t);
+      // ---- layer 1
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        BFrag bf[1];
+        split_pair(xt[2 * kk], xt[2 * kk + 1], bf[0]);
+        split_kstep<1, NKK, 0, MPNN_NT>(W1s, kk, lane, bf, h1);
+      }
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t) {
+        const f32x4 p = row_tile(Pi, t);
+        h1[t][0] = DEC ? (h1[t][0] * sc + p) : (h1[t][0] + p);
+      }
+      BFrag hb[NKK][1];
+      tile_to_bfrag<MPNN_NT, 1, true>(h1, hb);
+      // ---- layer 2
+      f32x4 y[MPNN_NT][1];
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t) y[t][0] = *reinterpret_cast<const f32x4*>(b2 + 16 * t + 4 * g);
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) split_kstep<1, NKK, 0, MPNN_NT>(W2s, kk, lane, hb[kk], y);
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t) gacc[t][0] += gelu4(y[t][0]) * w;
+    }
+    float* gout = gsum + (size_t)node * MPNN_H;
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      f32x4 sm = gacc[t][0];
+      sm.x = column_sum(sm.x); sm.y = column_sum(sm.y); sm.z = column_sum(sm.z); sm.w = column_sum(sm.w);
+      if (col == 0) *reinterpret_cast<f32x4*>(gout + 16 * t + 4 * g) = sm;
+    }
+    if (!DEC) {
+      wsum = column_sum(wsum);
+      if (lane == 0) cnt[node] = wsum;
+    }
+  }
+}
+
 // ===========================================================================
 // C ABI launchers
 // ===========================================================================
@@ -359,6 +476,13 @@ extern "C" int mpnn_enc_message(const float* hE_frag, const float* PQ, int ldpq,
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && ldpq >= 128 && mult4(ldpq, offP, offQ),
                  "mpnn_enc_message: bad sizes (strides/offsets must be multiples of 4 floats)");
   const int N = B * L, KT = (K + 15) / 16;
+  if (MPNN_MSG_TILEWISE || KT > 3) {
+    dim3 grid(edge_grid(N, MPNN_MSGT_WAVES)), block(MPNN_MSGT_WAVES * 64);
+    hipLaunchKernelGGL((k_message_tiles<false>), grid, block, 0, (hipStream_t)stream, (const f32x4*)hE_frag, PQ, ldpq,
+                       offP, PQ, ldpq, offQ, (const float*)nullptr, 0, 0, (const int*)nullptr, E_idx32, mask,
+                       edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2, N, L, K, KT, gsum, cnt);
+    MPNN_LAUNCH_CHECK();
+  }
   dim3 grid(edge_grid(N, MPNN_MSG_WAVES)), block(MPNN_MSG_WAVES * 64);
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, false>), grid, block, 0, (hipStream_t)stream,
                                      (const f32x4*)hE_frag, PQ, ldpq, offP, PQ, ldpq, offQ, (const float*)nullptr, 0, 0,
@@ -393,6 +517,13 @@ extern "C" int mpnn_dec_message(const float* hE_frag, const float* PQ, int ldpq,
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && mult4(ldpq, offPa, offA, ldenc, offEnc),
                  "mpnn_dec_message: bad sizes (strides/offsets must be multiples of 4 floats)");
   const int N = B * L, KT = (K + 15) / 16;
+  if (MPNN_MSG_TILEWISE || KT > 3) {
+    dim3 grid(edge_grid(N, MPNN_MSGT_WAVES)), block(MPNN_MSGT_WAVES * 64);
+    hipLaunchKernelGGL((k_message_tiles<true>), grid, block, 0, (hipStream_t)stream, (const f32x4*)hE_frag, PQ, ldpq,
+                       offPa, PQ, ldpq, offA, PVenc, ldenc, offEnc, rank, E_idx32, mask, edge_mask,
+                       (const h8*)W1b_packed, (const h8*)W2_packed, b2, N, L, K, KT, gsum, (float*)nullptr);
+    MPNN_LAUNCH_CHECK();
+  }
   dim3 grid(edge_grid(N, MPNN_MSG_WAVES)), block(MPNN_MSG_WAVES * 64);
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, true>), grid, block, 0, (hipStream_t)stream,
                                      (const f32x4*)hE_frag, PQ, ldpq, offPa, PQ, ldpq, offA, PVenc, ldenc, offEnc, rank,

@@ -84,7 +84,7 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
     BFrag xb[NKK][1];
     tile_to_bfrag<MPNN_NT, 1, false>(gs, xb);
     prefetch();
-    split_gemm<1, NKK, 0, MPNN_NT>(lds + (k & 1) * WSPLIT, lane, xb, dh);
+    split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT + lane, xb, dh);
     retire();
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) h[t][0] = h[t][0] + dh[t][0] * inv_scale;
@@ -100,12 +100,12 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
       for (int t = 0; t < MPNN_NT; ++t)
         hid[t][0] = *reinterpret_cast<const f32x4*>(bin + 128 * q + 16 * t + 4 * g);
       prefetch();
-      split_gemm<1, NKK, 0, MPNN_NT>(lds + (k & 1) * WSPLIT, lane, xb, hid);
+      split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT + lane, xb, hid);
       retire();
       BFrag hb[NKK][1];
       tile_to_bfrag<MPNN_NT, 1, true>(hid, hb);
       prefetch();
-      split_gemm<1, NKK, 0, MPNN_NT>(lds + (k & 1) * WSPLIT, lane, hb, o);
+      split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT + lane, hb, o);
       retire();
     }
     tile_layernorm<1>(o, ln2w, ln2b, lane);
@@ -124,7 +124,7 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) y[t][0] = *reinterpret_cast<const f32x4*>(bproj + p * MPNN_H + 16 * t + 4 * g);
     prefetch();
-    split_gemm<1, NKK, 0, MPNN_NT>(lds + (k & 1) * WSPLIT, lane, pb, y);
+    split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT + lane, pb, y);
     retire();
     if (add_table && p == add_block) {  // decoder: fold the sequence term W1c W_s[S_n] into the A block
       const float* tr = add_table + (size_t)add_idx[nd] * ld_table + off_table + 4 * g;

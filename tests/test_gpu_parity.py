@@ -127,6 +127,25 @@ def test_forward_vs_reference_golden(name):
     assert_close(out["log_probs"].cpu().numpy()[~mask], rec["log_probs"][~mask], 1e-6, 1e-6, "padded rows")
 
 
+@pytest.mark.parametrize("k,L,lengths", [(20, 72, [72, 40]), (64, 80, [80, 70]), (33, 50, [50, 50])])
+def test_other_neighbour_counts_vs_oracle(k, L, lengths):
+    """K = 20 / 33 / 64: 2-, 3- and 4-tile neighbour lists (the last goes through the tile-wise message kernel)."""
+    from mpnn_amd import engine
+    from mpnn_amd.synthetic import synthetic_batch
+
+    kw = dict(k_neighbors=k)
+    model = build_model(kw)
+    b = synthetic_batch(B=2, L=L, seed=40 + k, lengths=lengths, n_chains=2, design_fraction=0.5)
+    rec = {n: v.numpy() for n, v in b.items()}
+    out = run_hip(model, rec)
+    ref = run_oracle(model, kw, rec)
+    same(out["E_idx"].cpu().numpy(), ref["E_idx"].numpy(), "E_idx")
+    same(out["mask_bw"].cpu().numpy(), ref["mask_bw"].numpy(), "mask_bw")
+    mask = rec["mask"].astype(bool)
+    assert_close(out["h_E_enc"][-1].cpu().numpy()[mask], ref["h_E_enc"][-1].numpy()[mask], 1e-4, 5e-5, "h_E")
+    assert_close(out["log_probs"].cpu().numpy(), ref["log_probs"].numpy(), LP_RTOL, LP_ATOL, "log_probs")
+
+
 def test_features_surface():
     """model.features(...) keeps the reference's return tuple (reference :309, :360)."""
     rec, kw = load_golden("g_all_B2_L128")

@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B kernel variants (built by tools/build_variant.sh): per-kernel ms/step for each variants/libmpnn_<tag>.so
+for so in variants/libmpnn_*.so; do
+  tag=$(basename $so .so); tag=${tag#libmpnn_}
+  MPNN_HIP_LIB=$PWD/$so timeout -k 10 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null > gpurun_out/ab_$tag.json || { echo "$tag FAILED"; continue; }
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/ab_$tag.json"))
+k=d["kernels_ms_per_step"]
+print(f"{'$tag':10s} step {d['ms_per_step']:6.3f} ms | " + " ".join(f"{n.replace('mpnn_','')}={v:.3f}" for n,v in k.items() if v>0.05))
+PY
+done

@@ -11,6 +11,6 @@ python - <<PY
 import json
 d=json.load(open("gpurun_out/bench_$tag.json"))
 print("res/s", d["value"], "ms/step", d["ms_per_step"])
-print("roofline", d["roofline"]["kernel"], d["roofline"]["avg_launch_ms"], "exec frac", d["roofline"]["executed_frac"])
+print("roofline", d["roofline"]["kernel"], d["roofline"]["avg_launch_ms"], "frac", d["roofline"]["frac"])
 print(d["kernels_ms_per_step"])
 PY
