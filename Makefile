@@ -4,7 +4,7 @@ ARCH  ?= gfx950
 CSRC  := mpnn_amd/csrc
 OUT   := mpnn_amd/libmpnn_hip.so
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wno-unused-result $(EXTRA)
-OBJS  := $(CSRC)/mpnn_featurizer.o $(CSRC)/mpnn_edge.o $(CSRC)/mpnn_node.o $(CSRC)/mpnn_abi.o
+OBJS  := $(CSRC)/mpnn_featurizer.o $(CSRC)/mpnn_edge.o $(CSRC)/mpnn_edge_bwd.o $(CSRC)/mpnn_node.o $(CSRC)/mpnn_abi.o
 
 all: $(OUT)
 
@@ -12,7 +12,10 @@ all: $(OUT)
 $(CSRC)/mpnn_featurizer.o: $(CSRC)/mpnn_featurizer.hip $(CSRC)/mpnn_common.h
 	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $< -o $@
 
-$(CSRC)/mpnn_edge.o: $(CSRC)/mpnn_edge.hip $(CSRC)/mpnn_common.h
+$(CSRC)/mpnn_edge.o: $(CSRC)/mpnn_edge.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(CSRC)/mpnn_edge_bwd.o: $(CSRC)/mpnn_edge_bwd.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/mpnn_abi.o: $(CSRC)/mpnn_abi.cpp

@@ -126,6 +126,55 @@ int mpnn_occupancy_mlp(const float* occ, const float* w0, const float* b0, const
 int mpnn_logits_log_softmax(const float* hV, const float* Wout_packed, const float* bias, int n_letters, int n_nodes,
                             float* log_probs, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Training step: per-edge kernels with saved pre-activations and their backward.  The reference differentiates
+ * EncLayer.forward (:73-95) / DecLayer.forward (:118-138) with torch autograd inside train.py:375-392; here the
+ * same gradients come from explicit kernels.  All *_frag arrays use hE's fragment layout; P / Row* / dP / out*
+ * are dense [n_nodes,128]; *_rows are row-major [n_nodes * 16 ceil(K/16)][128].  K <= 48.
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* Forward of mpnn_enc_message (dec = 0: Row = RowA[j], cnt written) or mpnn_dec_message (dec = 1: Row = RowA[j]
+ * where rank[j] < rank[i], else RowB[j]) that also stores a1 = P + s (Row + W1b e) and a2 = W2 gelu(a1) + b2. */
+int mpnn_message_train(int dec, const float* hE_frag, const float* P, const float* RowA, const float* RowB,
+                       const int32_t* rank, const int32_t* E_idx32, const float* mask, const float* edge_mask,
+                       const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K,
+                       float* gsum, float* cnt, float* a1_frag, float* a2_frag, void* stream);
+
+/* Forward of mpnn_enc_edge_update, out of place, storing a1', a2' and the pre-LayerNorm sum z (:90-95). */
+int mpnn_enc_edge_update_train(const float* hE_frag, const float* P, const float* Q, const int32_t* E_idx32,
+                               const float* W11b_packed, const float* W12_packed, const float* b12,
+                               const float* W13_packed, const float* b13, const float* ln_w, const float* ln_b, int B,
+                               int L, int K, float* hE_out, float* a1_frag, float* a2_frag, float* z_frag,
+                               void* stream);
+
+/* Backward of the message MLP: given dgsum, writes da2 (fragment), s-scaled da1 rows, dP = sum_k da1, and
+ * dE (+)= W1b^T (s da1).  W2T / W1bT are mpnn_pack_linear_split of the TRANSPOSED matrices.
+ * amax2[0..1] (zero them first) receive max |da2| and max |da1 rows| as fp32: mpnn_edge_wgrad's A_absmax. */
+int mpnn_message_bwd(int dec, const float* dgsum, const float* a1_frag, const float* a2_frag, const int32_t* E_idx32,
+                     const float* mask, const float* edge_mask, const float* W2T_packed, const float* W1bT_packed,
+                     int B, int L, int K, float* da2_frag, float* da1_rows, float* dP, float* dE_frag, int accumulate,
+                     float* amax2, void* stream);
+
+/* Backward of the edge update: LayerNorm', W13^T, W12^T, W11b^T; dln[0:128] += d ln_w, dln[128:256] += d ln_b.
+ * dE_frag may alias dy_frag.  amax3[0..2] (zero them first) receive max |dz|, |da2|, |da1 rows|. */
+int mpnn_enc_edge_update_bwd(const float* dy_frag, const float* z_frag, const float* a2_frag, const float* a1_frag,
+                             const float* ln_w, const float* W13T_packed, const float* W12T_packed,
+                             const float* W11bT_packed, int B, int L, int K, float* dz_frag, float* da2_frag,
+                             float* da1_rows, float* dP, float* dE_frag, float* dln, float* amax3, void* stream);
+
+/* dW[fo][fi] += sum_edges A[e][fo] * f(B[e][fi]), dbias[fo] += sum_edges A[e][fo]  (the nn.Linear weight / bias
+ * gradients of one per-edge 128x128 layer).  A: fragment layout, or rows when a_rows != 0; B: fragment layout,
+ * f = GELU when b_gelu != 0.  dW [128,128] row-major, accumulated with atomics (zero it first); dbias may be NULL.
+ * A_absmax: device scalar >= max |A| (any positive value of that magnitude): gradients are tiny, so A is scaled by a
+ * power of two derived from it before the f16 hi/lo split and the result scaled back. */
+int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax, const float* B_frag, int b_gelu, int n_nodes,
+                    int K, float* dW, float* dbias, void* stream);
+
+/* Gradient of the neighbour gather h[E_idx]: outA[j] = sum of rows[inv_row[m]] for m in [inv_ptr[j], inv_ptr[j+1]),
+ * split between outA (sel[m] == 0) and outB (sel[m] != 0) when sel is given (decoder: which block the edge read). */
+int mpnn_gather_rows(const float* rows, const int32_t* inv_ptr, const int32_t* inv_row, const unsigned char* sel,
+                     int n_nodes, float* outA, float* outB, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

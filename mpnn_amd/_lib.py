@@ -38,6 +38,13 @@ SIGNATURES = {
                          _P, _I, _I, _P, _I, _I, _P, _P, _P],
     "mpnn_occupancy_mlp": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "mpnn_logits_log_softmax": [_P, _P, _P, _I, _I, _P, _P],
+    # training step (forward with saved pre-activations, backward, weight gradients)
+    "mpnn_message_train": [_I] + [_P] * 11 + [_I] * 3 + [_P] * 5,
+    "mpnn_enc_edge_update_train": [_P] * 11 + [_I] * 3 + [_P] * 5,
+    "mpnn_message_bwd": [_I] + [_P] * 8 + [_I] * 3 + [_P] * 4 + [_I, _P, _P],
+    "mpnn_enc_edge_update_bwd": [_P] * 8 + [_I] * 3 + [_P] * 8,
+    "mpnn_edge_wgrad": [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P],
+    "mpnn_gather_rows": [_P] * 4 + [_I] + [_P] * 3,
 }
 
 _lib = None

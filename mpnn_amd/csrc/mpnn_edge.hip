@@ -20,7 +20,7 @@
 //     current residue's last read of it, its index/mask scalars one phase earlier,
 //   * the edge update streams its third weight matrix from L2 three fragments ahead.
 // Two waves per SIMD (8-wave workgroups) let one wave's GELU / reductions run under the other's MFMAs.
-#include "mpnn_common.h"
+#include "mpnn_edge_common.h"
 
 #ifndef MPNN_MSG_WAVES
 #define MPNN_MSG_WAVES 8
@@ -33,25 +33,6 @@
 #ifndef MPNN_UPD_WAVES
 #define MPNN_UPD_WAVES 8
 #endif
-
-// make a (uniform) pointer opaque once per loop iteration: keeps LICM from hoisting hundreds of
-// loop-invariant weight / bias loads out of the persistent loop and pinning them in registers
-#define LAUNDER(p) asm volatile("" : "+s"(p))
-#define FENCE() __builtin_amdgcn_sched_barrier(0)
-
-__device__ __forceinline__ void lds_fill(h8* dst, const h8* __restrict__ src, int n) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-}
-
-__device__ __forceinline__ f32x4 row_tile(const float* row, int t) {
-#ifdef MPNN_ABL_NOROW  // timing-only ablation
-  return f32x4{0.1f, 0.2f, 0.3f, 0.4f};
-#endif
-  return *reinterpret_cast<const f32x4*>(row + 16 * t);
-}
-
-constexpr int NKK = MPNN_NT / 2;       // k-steps (32 features) per 128-wide layer
-constexpr int WSPLIT = 8 * NKK * 2 * 64;  // h8 elements of one packed 128x128 matrix (64 KiB)
 
 // layer 1 of every edge MLP: acc += W1b * hE[node]; hE feature tiles stream from HBM one k-step
 // (two tiles) ahead of their MFMAs and are split to f16 hi/lo on the fly
@@ -107,13 +88,16 @@ __device__ __forceinline__ void reduce_store(f32x4 (&y)[MPNN_NT][KT], const floa
 //   enc: Row = Q_j, s = 1, w = mask_i mask_j edge_mask_ik, cnt = sum_k w       (:75-81, :467-470)
 //   dec: Row by decoding rank (see header), s = mask_i edge_mask_ik, w = [k < K] (:478-525, :121-127)
 // ---------------------------------------------------------------------------
-template <int KT, bool DEC>
+// SAVE (training forward): the two pre-activations a1 = P + s (Row + W1b e) and a2 = W2 gelu(a1) + b2 are
+// also written out, in the fragment layout of hE, for the backward kernels of mpnn_edge_bwd.hip.
+template <int KT, bool DEC, bool SAVE>
 __global__ void __launch_bounds__(MPNN_MSG_WAVES * 64)
 k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp, int offP,
           const float* __restrict__ Abuf, int lda, int offA, const float* __restrict__ Bbuf, int ldb, int offB,
           const int* __restrict__ rank, const int* __restrict__ E_idx, const float* __restrict__ mask,
           const float* __restrict__ edge_mask, const h8* __restrict__ W1b, const h8* __restrict__ W2,
-          const float* __restrict__ b2, int N, int L, int K, float* __restrict__ gsum, float* __restrict__ cnt) {
+          const float* __restrict__ b2, int N, int L, int K, float* __restrict__ gsum, float* __restrict__ cnt,
+          f32x4* __restrict__ sv1, f32x4* __restrict__ sv2) {
   __shared__ h8 lds[2 * WSPLIT];
   lds_fill(lds, W1b, WSPLIT);
   lds_fill(lds + WSPLIT, W2, WSPLIT);
@@ -175,6 +159,13 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
       for (int c = 0; c < KT; ++c) h1[t][c] = DEC ? (h1[t][c] * s[c] + p[t]) : (h1[t][c] + p[t]);
+    if (SAVE) {
+      f32x4* o = sv1 + (size_t)node * (MPNN_NT * KT * 64) + lane;
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) o[(t * KT + c) * 64] = h1[t][c];
+    }
     BFrag hb[NKK][KT];
     tile_to_bfrag<MPNN_NT, KT, true>(h1, hb);
     // next residue's scalars (their loads fly under layer 2)
@@ -189,6 +180,13 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
       for (int c = 0; c < KT; ++c) y[t][c] = bb;
     }
     split_gemm<KT, NKK, 0, MPNN_NT>(W2s, lane, hb, y);
+    if (SAVE) {
+      f32x4* o = sv2 + (size_t)node * (MPNN_NT * KT * 64) + lane;
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) o[(t * KT + c) * 64] = y[t][c];
+    }
     // h1 is free: gather the next residue's rows under the GELU + reduction below
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
@@ -215,12 +213,16 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 //   e_ik <- LN3(e_ik + W13 gelu(W12 gelu(P'_i + Q'_j + W11b e_ik) + b12) + b13)
 // W11b, W12 in LDS; W13 streams from L2 (A fragments three steps ahead of their MFMAs).
 // ---------------------------------------------------------------------------
-template <int KT>
+// SAVE (training forward): out of place (hE_out), and a1', a2' and the pre-LayerNorm sum z are written out.
+template <int KT, bool SAVE>
 __global__ void __launch_bounds__(MPNN_UPD_WAVES * 64)
-k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ PQ, int ldpq, int offP, int offQ,
+k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp, int offP,
+                  const float* __restrict__ Qb, int ldq, int offQ,
                   const int* __restrict__ E_idx, const h8* __restrict__ W11b, const h8* __restrict__ W12,
                   const float* __restrict__ b12, const h8* __restrict__ W13, const float* __restrict__ b13,
-                  const float* __restrict__ ln_w, const float* __restrict__ ln_b, int N, int L) {
+                  const float* __restrict__ ln_w, const float* __restrict__ ln_b, int N, int L,
+                  f32x4* __restrict__ hE_out, f32x4* __restrict__ sv1, f32x4* __restrict__ sv2,
+                  f32x4* __restrict__ svz) {
   __shared__ h8 lds[2 * WSPLIT];
   lds_fill(lds, W11b, WSPLIT);
   lds_fill(lds + WSPLIT, W12, WSPLIT);
@@ -238,7 +240,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ PQ, int ldpq
     const int b = nd / L;
 #pragma unroll
     for (int c = 0; c < KT; ++c)
-      row[c] = PQ + (size_t)(b * L + E_idx[(size_t)nd * Kp + 16 * c + col]) * ldpq + offQ + 4 * g;
+      row[c] = Qb + (size_t)(b * L + E_idx[(size_t)nd * Kp + 16 * c + col]) * ldq + offQ + 4 * g;
   };
 
   const float* row[KT];
@@ -261,7 +263,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ PQ, int ldpq
     f32x4* x = hE + (size_t)node * (MPNN_NT * KT * 64) + lane;
     f32x4 p[MPNN_NT];
     {
-      const float* Pi = PQ + (size_t)node * ldpq + offP + 4 * g;
+      const float* Pi = Pb + (size_t)node * ldp + offP + 4 * g;
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t) p[t] = row_tile(Pi, t);
     }
@@ -275,6 +277,13 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ PQ, int ldpq
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
       for (int c = 0; c < KT; ++c) h1[t][c] += p[t];
+    const size_t soff = (size_t)node * (MPNN_NT * KT * 64) + lane;
+    if (SAVE) {
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) sv1[soff + (t * KT + c) * 64] = h1[t][c];
+    }
     BFrag hb[NKK][KT];
     tile_to_bfrag<MPNN_NT, KT, true>(h1, hb);
     const float* rown[KT];
@@ -287,6 +296,12 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ PQ, int ldpq
       for (int c = 0; c < KT; ++c) h2[t][c] = bb;
     }
     split_gemm<KT, NKK, 0, MPNN_NT>(W2s, lane, hb, h2);
+    if (SAVE) {
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) sv2[soff + (t * KT + c) * 64] = h2[t][c];
+    }
     // residual e -> layer 3's initial accumulator (loads fly under the GELU + split of h2)
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
@@ -326,13 +341,17 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ PQ, int ldpq
     for (int t = 0; t < MPNN_NT; ++t) {
       const f32x4 bb = *reinterpret_cast<const f32x4*>(b13 + 16 * t + 4 * g);
 #pragma unroll
-      for (int c = 0; c < KT; ++c) h1[t][c] += bb;
+      for (int c = 0; c < KT; ++c) {
+        h1[t][c] += bb;
+        if (SAVE) svz[soff + (t * KT + c) * 64] = h1[t][c];
+      }
     }
     tile_layernorm<KT>(h1, ln_w, ln_b, lane);
+    f32x4* xo = SAVE ? hE_out + soff : x;
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-      for (int c = 0; c < KT; ++c) x[(t * KT + c) * 64] = h1[t][c];
+      for (int c = 0; c < KT; ++c) xo[(t * KT + c) * 64] = h1[t][c];
   }
 }
 
@@ -443,30 +462,6 @@ k_message_tiles(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, in
 // ===========================================================================
 // C ABI launchers
 // ===========================================================================
-static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
-
-static int edge_grid(int N, int waves) {
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
-  const int want = ceil_div(N, waves);
-  return want < cus ? want : cus;
-}
-
-#define KT_DISPATCH(KT, CALL)   \
-  switch (KT) {                 \
-    case 1: { constexpr int kKT = 1; CALL; } break; \
-    case 2: { constexpr int kKT = 2; CALL; } break; \
-    case 3: { constexpr int kKT = 3; CALL; } break; \
-    default: { constexpr int kKT = 4; CALL; } break; \
-  }
-
-static bool mult4(int a, int b = 0, int c = 0, int d = 0, int e = 0, int f = 0) {
-  return ((a | b | c | d | e | f) & 3) == 0;
-}
-
 extern "C" int mpnn_enc_message(const float* hE_frag, const float* PQ, int ldpq, int offP, int offQ,
                                 const int32_t* E_idx32, const float* mask, const float* edge_mask,
                                 const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K,
@@ -484,10 +479,10 @@ extern "C" int mpnn_enc_message(const float* hE_frag, const float* PQ, int ldpq,
     MPNN_LAUNCH_CHECK();
   }
   dim3 grid(edge_grid(N, MPNN_MSG_WAVES)), block(MPNN_MSG_WAVES * 64);
-  KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, false>), grid, block, 0, (hipStream_t)stream,
+  KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, false, false>), grid, block, 0, (hipStream_t)stream,
                                      (const f32x4*)hE_frag, PQ, ldpq, offP, PQ, ldpq, offQ, (const float*)nullptr, 0, 0,
                                      (const int*)nullptr, E_idx32, mask, edge_mask, (const h8*)W1b_packed,
-                                     (const h8*)W2_packed, b2, N, L, K, gsum, cnt));
+                                     (const h8*)W2_packed, b2, N, L, K, gsum, cnt, (f32x4*)nullptr, (f32x4*)nullptr));
   MPNN_LAUNCH_CHECK();
 }
 
@@ -501,9 +496,10 @@ extern "C" int mpnn_enc_edge_update(float* hE_frag, const float* PQ, int ldpq, i
                  "mpnn_enc_edge_update: bad sizes (strides/offsets must be multiples of 4 floats)");
   const int N = B * L, KT = (K + 15) / 16;
   dim3 grid(edge_grid(N, MPNN_UPD_WAVES)), block(MPNN_UPD_WAVES * 64);
-  KT_DISPATCH(KT, hipLaunchKernelGGL((k_enc_edge_update<kKT>), grid, block, 0, (hipStream_t)stream, (f32x4*)hE_frag, PQ,
-                                     ldpq, offP, offQ, E_idx32, (const h8*)W11b_packed, (const h8*)W12_packed,
-                                     b12, (const h8*)W13_packed, b13, ln_w, ln_b, N, L));
+  KT_DISPATCH(KT, hipLaunchKernelGGL((k_enc_edge_update<kKT, false>), grid, block, 0, (hipStream_t)stream,
+                                     (f32x4*)hE_frag, PQ, ldpq, offP, PQ, ldpq, offQ, E_idx32, (const h8*)W11b_packed,
+                                     (const h8*)W12_packed, b12, (const h8*)W13_packed, b13, ln_w, ln_b, N, L,
+                                     (f32x4*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr));
   MPNN_LAUNCH_CHECK();
 }
 
@@ -525,9 +521,54 @@ extern "C" int mpnn_dec_message(const float* hE_frag, const float* PQ, int ldpq,
     MPNN_LAUNCH_CHECK();
   }
   dim3 grid(edge_grid(N, MPNN_MSG_WAVES)), block(MPNN_MSG_WAVES * 64);
-  KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, true>), grid, block, 0, (hipStream_t)stream,
+  KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, true, false>), grid, block, 0, (hipStream_t)stream,
                                      (const f32x4*)hE_frag, PQ, ldpq, offPa, PQ, ldpq, offA, PVenc, ldenc, offEnc, rank,
                                      E_idx32, mask, edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2,
-                                     N, L, K, gsum, (float*)nullptr));
+                                     N, L, K, gsum, (float*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr));
+  MPNN_LAUNCH_CHECK();
+}
+
+// ---- training forward: same kernels, pre-activations saved for mpnn_edge_bwd.hip (K <= 48) ----
+extern "C" int mpnn_message_train(int dec, const float* hE_frag, const float* P, const float* RowA, const float* RowB,
+                                  const int32_t* rank, const int32_t* E_idx32, const float* mask,
+                                  const float* edge_mask, const float* W1b_packed, const float* W2_packed,
+                                  const float* b2, int B, int L, int K, float* gsum, float* cnt, float* a1_frag,
+                                  float* a2_frag, void* stream) {
+  MPNN_CHECK_ARG(hE_frag && P && RowA && E_idx32 && mask && W1b_packed && W2_packed && b2 && gsum && a1_frag && a2_frag,
+                 "mpnn_message_train: null pointer");
+  MPNN_CHECK_ARG(dec ? (RowB && rank) : (cnt != nullptr), "mpnn_message_train: decoder needs RowB and rank, encoder cnt");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 48, "mpnn_message_train: bad sizes (training path covers K <= 48)");
+  const int N = B * L, KT = (K + 15) / 16;
+  dim3 grid(edge_grid(N, MPNN_MSG_WAVES)), block(MPNN_MSG_WAVES * 64);
+  if (dec) {
+    KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, true, true>), grid, block, 0, (hipStream_t)stream,
+                                       (const f32x4*)hE_frag, P, 128, 0, RowA, 128, 0, RowB, 128, 0, rank, E_idx32,
+                                       mask, edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2, N, L, K, gsum,
+                                       (float*)nullptr, (f32x4*)a1_frag, (f32x4*)a2_frag));
+  } else {
+    KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, false, true>), grid, block, 0, (hipStream_t)stream,
+                                       (const f32x4*)hE_frag, P, 128, 0, RowA, 128, 0, (const float*)nullptr, 0, 0,
+                                       (const int*)nullptr, E_idx32, mask, edge_mask, (const h8*)W1b_packed,
+                                       (const h8*)W2_packed, b2, N, L, K, gsum, cnt, (f32x4*)a1_frag, (f32x4*)a2_frag));
+  }
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_enc_edge_update_train(const float* hE_frag, const float* P, const float* Q, const int32_t* E_idx32,
+                                          const float* W11b_packed, const float* W12_packed, const float* b12,
+                                          const float* W13_packed, const float* b13, const float* ln_w,
+                                          const float* ln_b, int B, int L, int K, float* hE_out, float* a1_frag,
+                                          float* a2_frag, float* z_frag, void* stream) {
+  MPNN_CHECK_ARG(hE_frag && P && Q && E_idx32 && W11b_packed && W12_packed && b12 && W13_packed && b13 && ln_w &&
+                     ln_b && hE_out && a1_frag && a2_frag && z_frag,
+                 "mpnn_enc_edge_update_train: null pointer");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 48 && hE_out != hE_frag,
+                 "mpnn_enc_edge_update_train: bad sizes (training path covers K <= 48, out of place)");
+  const int N = B * L, KT = (K + 15) / 16;
+  dim3 grid(edge_grid(N, MPNN_UPD_WAVES)), block(MPNN_UPD_WAVES * 64);
+  KT_DISPATCH(KT, hipLaunchKernelGGL((k_enc_edge_update<kKT, true>), grid, block, 0, (hipStream_t)stream,
+                                     (f32x4*)hE_frag, P, 128, 0, Q, 128, 0, E_idx32, (const h8*)W11b_packed,
+                                     (const h8*)W12_packed, b12, (const h8*)W13_packed, b13, ln_w, ln_b, N, L,
+                                     (f32x4*)hE_out, (f32x4*)a1_frag, (f32x4*)a2_frag, (f32x4*)z_frag));
   MPNN_LAUNCH_CHECK();
 }

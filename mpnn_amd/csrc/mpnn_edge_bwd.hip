@@ -1,0 +1,529 @@
+// Backward of the per-edge kernels (training step; reference: src/mpnn/models/model_utils.py EncLayer :48-95,
+// DecLayer :98-138 differentiated by torch autograd in the reference's training loop).
+//
+// The training forward (mpnn_message_train / mpnn_enc_edge_update_train, mpnn_edge.hip) saves the MLP
+// pre-activations in the fragment layout.  Backward of one MLP is the same register-resident chain as
+// forward, run with transposed weights:
+//   message:   da2 = dgsum_i w_ik gelu'(a2)          dg1 = W2^T da2        da1 = dg1 gelu'(a1)
+//              dP_i = sum_k da1      dRow_ik = s_ik da1      de_ik (+)= W1b^T (s_ik da1)
+//   update:    dz = LayerNorm'(dy; z)   dg2 = W13^T dz   da2 = dg2 gelu'(a2)   dg1 = W12^T da2
+//              da1 = dg1 gelu'(a1)      dP'_i = sum_k da1     dQ'_j += da1     de_ik = dz + W11b^T da1
+// The per-edge gradients da* are written out once (fragment layout, or row-major "natural" rows where a
+// scatter to neighbour nodes follows) and feed
+//   k_wgrad        dW[fo][fi] (+)= sum_edges A[fo, e] B[fi, e]  (split-f16 MFMA over LDS-transposed tiles)
+//   k_gather_rows  dRow_j = sum over the edges that point at j (inverse neighbour list; no atomics)
+#include "mpnn_edge_common.h"
+
+#define MPNN_BWD_WAVES 8
+
+// d/dx [x Phi(x)] = Phi(x) + x phi(x); same erfc approximation and the same exponential as gelu()
+__device__ __forceinline__ float gelu_grad(float x) {
+  const float z = x * 0.70710678118654752440f;
+  const float az = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float zs = z * 1.20112240878644977f;
+  const float e = __builtin_amdgcn_exp2f(-(zs * zs));  // exp(-x^2 / 2)
+  const float q = 0.5f * (p * e);                      // Phi(-|x|)
+  const float Phi = x >= 0.f ? 1.0f - q : q;
+  return fmaf(x * 0.39894228040143267794f, e, Phi);
+}
+
+__device__ __forceinline__ f32x4 gelu_grad4(f32x4 v) {
+  f32x4 o;
+  o.x = gelu_grad(v.x); o.y = gelu_grad(v.y); o.z = gelu_grad(v.z); o.w = gelu_grad(v.w);
+  return o;
+}
+
+// Gradients are tiny (the loss is divided by 2000, train.py:72) while the f16 hi/lo split only resolves 6e-8
+// absolute below 6e-5.  Every gradient tile is therefore multiplied by a power of two (exact) that brings the
+// wave's largest magnitude to [2^12, 2^13) before it is split, and the fp32 product is scaled back.
+__device__ __forceinline__ float pow2_scale_from_bits(unsigned mbits) {
+  const int e = (int)(mbits >> 23) & 0xff;
+  return e < 40 ? 1.0f : __int_as_float((266 - e) << 23);
+}
+__device__ __forceinline__ float pow2_inverse(float scale) {
+  return __int_as_float((254 << 23) - __float_as_int(scale));
+}
+// wave-wide max |v| of a register tile (returned as float bits: non-negative floats order like unsigneds)
+template <int KT>
+__device__ __forceinline__ unsigned tile_absmax_bits(const f32x4 (&d)[MPNN_NT][KT]) {
+  float m = 0.f;
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+    for (int c = 0; c < KT; ++c)
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(d[t][c].x), fabsf(d[t][c].y))), fmaxf(fabsf(d[t][c].z), fabsf(d[t][c].w)));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  return (unsigned)__float_as_int(m);
+}
+// scaled split of a gradient tile; returns the factor that undoes the scaling
+template <int KT>
+__device__ __forceinline__ float grad_to_bfrag(f32x4 (&d)[MPNN_NT][KT], BFrag (&db)[NKK][KT], unsigned* amax_lds) {
+  const unsigned mb = tile_absmax_bits<KT>(d);
+  if (amax_lds && (threadIdx.x & 63) == 0) atomicMax(amax_lds, mb);
+  const float sc = pow2_scale_from_bits(mb);
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+    for (int c = 0; c < KT; ++c) d[t][c] *= sc;
+  tile_to_bfrag<MPNN_NT, KT, false>(d, db);
+  return pow2_inverse(sc);
+}
+
+template <int KT>
+__device__ __forceinline__ void zero_tile(f32x4 (&y)[MPNN_NT][KT]) {
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+    for (int c = 0; c < KT; ++c) y[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// y <- y * gelu'(a) with a streamed from the saved pre-activations; per-feature sums over the residue's edges
+// go to dP (the h_i projection's gradient); the (optionally s-scaled) rows are written row-major for the gather
+template <int KT, bool SCALE>
+__device__ __forceinline__ void first_layer_grad(f32x4 (&y)[MPNN_NT][KT], float unscale, const f32x4* __restrict__ a,
+                                                 const float (&s)[KT], float* __restrict__ dP, float* __restrict__ nat,
+                                                 int lane) {
+  const int g = lane >> 4, col = lane & 15;
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) {
+    f32x4 ps = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      y[t][c] *= gelu_grad4(a[(t * KT + c) * 64]) * unscale;
+      ps += y[t][c];
+      if (SCALE) y[t][c] *= s[c];
+      *reinterpret_cast<f32x4*>(nat + (size_t)(16 * c + col) * MPNN_H + 16 * t + 4 * g) = y[t][c];
+    }
+    ps.x = column_sum(ps.x); ps.y = column_sum(ps.y); ps.z = column_sum(ps.z); ps.w = column_sum(ps.w);
+    if (col == 0) *reinterpret_cast<f32x4*>(dP + 16 * t + 4 * g) = ps;
+    FENCE();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// message backward (encoder DEC = false, decoder DEC = true)
+// ---------------------------------------------------------------------------
+template <int KT, bool DEC>
+__global__ void __launch_bounds__(MPNN_BWD_WAVES * 64)
+k_message_bwd(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, const f32x4* __restrict__ a2,
+              const int* __restrict__ E_idx, const float* __restrict__ mask, const float* __restrict__ edge_mask,
+              const h8* __restrict__ W2T, const h8* __restrict__ W1bT, int N, int L, int K,
+              f32x4* __restrict__ da2, float* __restrict__ da1_nat, float* __restrict__ dP, f32x4* __restrict__ dE,
+              int accumulate, unsigned* __restrict__ amax) {
+  __shared__ h8 lds[2 * WSPLIT];
+  __shared__ unsigned amax_l[2];
+  lds_fill(lds, W2T, WSPLIT);
+  lds_fill(lds + WSPLIT, W1bT, WSPLIT);
+  if (threadIdx.x < 2) amax_l[threadIdx.x] = 0u;
+  __syncthreads();
+  const h8* W2s = lds;
+  const h8* W1s = lds + WSPLIT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  constexpr int Kp = KT * 16;
+  const int stride = gridDim.x * MPNN_BWD_WAVES;
+  for (int node = blockIdx.x * MPNN_BWD_WAVES + wave; node < N; node += stride) {
+    LAUNDER(dgsum);
+    const int b = node / L;
+    const float mi = mask[node];
+    float s[KT], w[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      const int e = 16 * c + col;
+      float em = 1.0f;
+      if (edge_mask && e < K) em = edge_mask[(size_t)node * K + e];
+      if (DEC) {
+        s[c] = mi * em;
+        w[c] = e < K ? 1.0f : 0.0f;
+      } else {
+        s[c] = 1.0f;
+        w[c] = e < K ? mi * mask[b * L + E_idx[(size_t)node * Kp + e]] * em : 0.0f;
+      }
+    }
+    const size_t off = (size_t)node * (MPNN_NT * KT * 64) + lane;
+    f32x4 d[MPNN_NT][KT];
+    {
+      const float* dg = dgsum + (size_t)node * MPNN_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t) {
+        const f32x4 gs = row_tile(dg, t);
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+          d[t][c] = gelu_grad4(a2[off + (t * KT + c) * 64]) * (gs * w[c]);
+          da2[off + (t * KT + c) * 64] = d[t][c];
+        }
+        FENCE();
+      }
+    }
+    BFrag db[NKK][KT];
+    float un = grad_to_bfrag<KT>(d, db, &amax_l[0]);
+    f32x4 y[MPNN_NT][KT];
+    zero_tile<KT>(y);
+    split_gemm<KT, NKK, 0, MPNN_NT>(W2s, lane, db, y);
+    first_layer_grad<KT, DEC>(y, un, a1 + off, s, dP + (size_t)node * MPNN_H, da1_nat + (size_t)node * Kp * MPNN_H,
+                              lane);
+    un = grad_to_bfrag<KT>(y, db, &amax_l[1]);
+    zero_tile<KT>(d);
+    split_gemm<KT, NKK, 0, MPNN_NT>(W1s, lane, db, d);
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        f32x4 v = d[t][c] * un;
+        if (accumulate) v += dE[off + (t * KT + c) * 64];
+        dE[off + (t * KT + c) * 64] = v;
+      }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) atomicMax(amax + threadIdx.x, amax_l[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------
+// encoder edge-update backward.  dE may alias dy (each wave reads its residue's dy before writing).
+// LayerNorm parameter gradients are reduced per workgroup in LDS, then added to dln[0:128] (weight) and
+// dln[128:256] (bias) with one atomic per entry and workgroup.
+// ---------------------------------------------------------------------------
+template <int KT>
+__global__ void __launch_bounds__(MPNN_BWD_WAVES * 64)
+k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __restrict__ a2,
+                  const f32x4* __restrict__ a1, const float* __restrict__ ln_w, const h8* __restrict__ W13T,
+                  const h8* __restrict__ W12T, const h8* __restrict__ W11bT, int N, f32x4* __restrict__ dz_out,
+                  f32x4* __restrict__ da2_out, float* __restrict__ da1_nat, float* __restrict__ dP, f32x4* dE,
+                  float* __restrict__ dln, unsigned* __restrict__ amax) {
+  __shared__ h8 lds[2 * WSPLIT];
+  __shared__ float lnacc[2 * MPNN_H];
+  __shared__ unsigned amax_l[3];
+  if (threadIdx.x < 3) amax_l[threadIdx.x] = 0u;
+  lds_fill(lds, W13T, WSPLIT);
+  lds_fill(lds + WSPLIT, W12T, WSPLIT);
+  if (threadIdx.x < 2 * MPNN_H) lnacc[threadIdx.x] = 0.f;
+  __syncthreads();
+  const h8* W3s = lds;
+  const h8* W2s = lds + WSPLIT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  constexpr int Kp = KT * 16;
+  const int stride = gridDim.x * MPNN_BWD_WAVES;
+  for (int node = blockIdx.x * MPNN_BWD_WAVES + wave; node < N; node += stride) {
+    LAUNDER(ln_w);
+    const h8* W1u = W11bT;
+    LAUNDER(W1u);
+    const size_t off = (size_t)node * (MPNN_NT * KT * 64) + lane;
+    f32x4 x[MPNN_NT][KT], d[MPNN_NT][KT];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        x[t][c] = z[off + (t * KT + c) * 64];
+        d[t][c] = dy[off + (t * KT + c) * 64];
+      }
+    // x <- xhat
+    float rstd[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      float sm = 0.f;
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t) sm += (x[t][c].x + x[t][c].y) + (x[t][c].z + x[t][c].w);
+      const float mean = quarter_sum(sm) * (1.0f / MPNN_H);
+      float q = 0.f;
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t) {
+        x[t][c] -= mean;
+        q += (x[t][c].x * x[t][c].x + x[t][c].y * x[t][c].y) + (x[t][c].z * x[t][c].z + x[t][c].w * x[t][c].w);
+      }
+      rstd[c] = rsqrtf(quarter_sum(q) * (1.0f / MPNN_H) + MPNN_LN_EPS);
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t) x[t][c] *= rstd[c];
+    }
+    // LayerNorm parameter gradients; d <- dxhat = dy * gamma
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(ln_w + 16 * t + 4 * g);
+      f32x4 sg = f32x4{0.f, 0.f, 0.f, 0.f}, sb = sg;
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        sg += d[t][c] * x[t][c];
+        sb += d[t][c];
+        d[t][c] *= gm;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float vg = column_sum(sg[r]), vb = column_sum(sb[r]);
+        if (col == 0) {
+          atomicAdd(&lnacc[16 * t + 4 * g + r], vg);
+          atomicAdd(&lnacc[MPNN_H + 16 * t + 4 * g + r], vb);
+        }
+      }
+      FENCE();
+    }
+    // dz = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat))
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t) {
+        m1 += (d[t][c].x + d[t][c].y) + (d[t][c].z + d[t][c].w);
+        const f32x4 pr = d[t][c] * x[t][c];
+        m2 += (pr.x + pr.y) + (pr.z + pr.w);
+      }
+      m1 = quarter_sum(m1) * (1.0f / MPNN_H);
+      m2 = quarter_sum(m2) * (1.0f / MPNN_H);
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t) {
+        d[t][c] = (d[t][c] - m1 - x[t][c] * m2) * rstd[c];
+        dz_out[off + (t * KT + c) * 64] = d[t][c];
+      }
+    }
+    BFrag db[NKK][KT];
+    float un = grad_to_bfrag<KT>(d, db, &amax_l[0]);
+    // ---- through W13, gelu'(a2)
+    zero_tile<KT>(x);
+    split_gemm<KT, NKK, 0, MPNN_NT>(W3s, lane, db, x);
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        x[t][c] *= gelu_grad4(a2[off + (t * KT + c) * 64]) * un;
+        da2_out[off + (t * KT + c) * 64] = x[t][c];
+      }
+      FENCE();
+    }
+    un = grad_to_bfrag<KT>(x, db, &amax_l[1]);
+    // ---- through W12, gelu'(a1)
+    zero_tile<KT>(d);
+    split_gemm<KT, NKK, 0, MPNN_NT>(W2s, lane, db, d);
+    float s1[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) s1[c] = 1.0f;
+    first_layer_grad<KT, false>(d, un, a1 + off, s1, dP + (size_t)node * MPNN_H, da1_nat + (size_t)node * Kp * MPNN_H,
+                                lane);
+    un = grad_to_bfrag<KT>(d, db, &amax_l[2]);
+    // ---- de = dz (residual) + W11b^T da1 ; W11b^T streams from L2
+    zero_tile<KT>(x);
+    split_gemm_stream<KT, NKK, MPNN_NT, 3>(W1u + lane, db, x);
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) dE[off + (t * KT + c) * 64] = x[t][c] * un + dz_out[off + (t * KT + c) * 64];
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * MPNN_H) unsafeAtomicAdd(dln + threadIdx.x, lnacc[threadIdx.x]);
+  if (threadIdx.x < 3) atomicMax(amax + threadIdx.x, amax_l[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient of one 128x128 per-edge matrix:
+//   dW[fo][fi] += sum_{node, e} A[node, e, fo] * Bt(B[node, e, fi]),   db[fo] += sum A[node, e, fo]
+// A: fragment layout (A_NAT = false) or row-major rows [node * Kp + e][128]; B: fragment layout, optionally
+// through GELU (the layer input was gelu(a)).  A workgroup (4 waves) stages one residue at a time into LDS as
+// f16 hi/lo planes [feature][edge] (edges contiguous = the MFMA k dimension), then each wave accumulates its
+// 2 x 8 output tiles with v_mfma_f32_16x16x16_f16 (3 products per tile: lo*hi + hi*lo + hi*hi).
+// ---------------------------------------------------------------------------
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+constexpr int WG_LDK = 52;  // padded edge stride (halves): 104-byte rows spread the 8-byte operand reads over banks
+
+template <bool A_NAT, bool B_GELU>
+__global__ void __launch_bounds__(256)
+k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigned* __restrict__ amax, int N, int KT,
+        float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ _Float16 sA[2][MPNN_H][WG_LDK];
+  __shared__ _Float16 sB[2][MPNN_H][WG_LDK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  const int Kp = KT * 16;
+  f32x4 acc[2][MPNN_NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MPNN_NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const f32x4* Af = reinterpret_cast<const f32x4*>(A);
+  const float sc = pow2_scale_from_bits(*amax), un = pow2_inverse(sc);  // see grad_to_bfrag
+  for (int node = blockIdx.x; node < N; node += gridDim.x) {
+    __syncthreads();  // previous residue's operand reads are done
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = 2 * wave + tt;
+      for (int c = 0; c < KT; ++c) {
+        f32x4 va, vb;
+        if (A_NAT)
+          va = *reinterpret_cast<const f32x4*>(A + ((size_t)node * Kp + 16 * c + col) * MPNN_H + 16 * t + 4 * g);
+        else
+          va = Af[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane];
+        vb = Bf[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane];
+        if (B_GELU) vb = gelu4(vb);
+        bacc[tt] += va;
+        va *= sc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const _Float16 ah = (_Float16)va[r], bh = (_Float16)vb[r];
+          sA[0][16 * t + 4 * g + r][16 * c + col] = ah;
+          sA[1][16 * t + 4 * g + r][16 * c + col] = (_Float16)(va[r] - (float)ah);
+          sB[0][16 * t + 4 * g + r][16 * c + col] = bh;
+          sB[1][16 * t + 4 * g + r][16 * c + col] = (_Float16)(vb[r] - (float)bh);
+        }
+      }
+    }
+    __syncthreads();
+    for (int c = 0; c < KT; ++c) {
+      h4 ah[2], al[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const h4*>(&sA[0][16 * (2 * wave + i) + col][16 * c + 4 * g]);
+        al[i] = *reinterpret_cast<const h4*>(&sA[1][16 * (2 * wave + i) + col][16 * c + 4 * g]);
+      }
+#pragma unroll
+      for (int j = 0; j < MPNN_NT; ++j) {
+        const h4 bh = *reinterpret_cast<const h4*>(&sB[0][16 * j + col][16 * c + 4 * g]);
+        const h4 bl = *reinterpret_cast<const h4*>(&sB[1][16 * j + col][16 * c + 4 * g]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(al[i], bh, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[i], bl, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[i], bh, acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MPNN_NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        unsafeAtomicAdd(dW + (size_t)(16 * (2 * wave + i) + 4 * g + r) * MPNN_H + 16 * j + col, acc[i][j][r] * un);
+  if (db) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = column_sum(bacc[tt][r]);
+        if (col == 0) unsafeAtomicAdd(db + 16 * (2 * wave + tt) + 4 * g + r, v);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// out[j] = sum of the rows listed for node j (inverse neighbour list: rows that gathered node j in forward).
+// sel (optional, per list entry): 0 -> outA, 1 -> outB  (decoder: row came from the A or the encoder block)
+// One wave per destination node, 512-byte coalesced row reads, four rows in flight.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_gather_rows(const float* __restrict__ rows, const int* __restrict__ inv_ptr, const int* __restrict__ inv_row,
+              const unsigned char* __restrict__ sel, int N, float* __restrict__ outA, float* __restrict__ outB) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= N) return;
+  const int m0 = inv_ptr[j], m1 = inv_ptr[j + 1];
+  float2 sa = make_float2(0.f, 0.f), sb = sa;
+  int m = m0;
+  for (; m + 4 <= m1; m += 4) {
+    float2 v[4];
+    int fl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = *reinterpret_cast<const float2*>(rows + (size_t)inv_row[m + u] * MPNN_H + 2 * lane);
+      fl[u] = sel ? sel[m + u] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (fl[u]) { sb.x += v[u].x; sb.y += v[u].y; } else { sa.x += v[u].x; sa.y += v[u].y; }
+    }
+  }
+  for (; m < m1; ++m) {
+    const float2 v = *reinterpret_cast<const float2*>(rows + (size_t)inv_row[m] * MPNN_H + 2 * lane);
+    if (sel && sel[m]) { sb.x += v.x; sb.y += v.y; } else { sa.x += v.x; sa.y += v.y; }
+  }
+  *reinterpret_cast<float2*>(outA + (size_t)j * MPNN_H + 2 * lane) = sa;
+  if (outB) *reinterpret_cast<float2*>(outB + (size_t)j * MPNN_H + 2 * lane) = sb;
+}
+
+// ===========================================================================
+// C ABI launchers
+// ===========================================================================
+extern "C" int mpnn_message_bwd(int dec, const float* dgsum, const float* a1_frag, const float* a2_frag,
+                                const int32_t* E_idx32, const float* mask, const float* edge_mask,
+                                const float* W2T_packed, const float* W1bT_packed, int B, int L, int K,
+                                float* da2_frag, float* da1_rows, float* dP, float* dE_frag, int accumulate,
+                                float* amax2, void* stream) {
+  MPNN_CHECK_ARG(dgsum && a1_frag && a2_frag && E_idx32 && mask && W2T_packed && W1bT_packed && da2_frag &&
+                     da1_rows && dP && dE_frag && amax2,
+                 "mpnn_message_bwd: null pointer");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 48, "mpnn_message_bwd: bad sizes (training path covers K <= 48)");
+  const int N = B * L, KT = (K + 15) / 16;
+  dim3 grid(edge_grid(N, MPNN_BWD_WAVES)), block(MPNN_BWD_WAVES * 64);
+  if (dec) {
+    KT_DISPATCH(KT > 3 ? 3 : KT,
+                hipLaunchKernelGGL((k_message_bwd<(kKT > 3 ? 3 : kKT), true>), grid, block, 0, (hipStream_t)stream, dgsum,
+                                   (const f32x4*)a1_frag, (const f32x4*)a2_frag, E_idx32, mask, edge_mask,
+                                   (const h8*)W2T_packed, (const h8*)W1bT_packed, N, L, K, (f32x4*)da2_frag, da1_rows,
+                                   dP, (f32x4*)dE_frag, accumulate, (unsigned*)amax2));
+  } else {
+    KT_DISPATCH(KT > 3 ? 3 : KT,
+                hipLaunchKernelGGL((k_message_bwd<(kKT > 3 ? 3 : kKT), false>), grid, block, 0, (hipStream_t)stream,
+                                   dgsum, (const f32x4*)a1_frag, (const f32x4*)a2_frag, E_idx32, mask, edge_mask,
+                                   (const h8*)W2T_packed, (const h8*)W1bT_packed, N, L, K, (f32x4*)da2_frag, da1_rows,
+                                   dP, (f32x4*)dE_frag, accumulate, (unsigned*)amax2));
+  }
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_enc_edge_update_bwd(const float* dy_frag, const float* z_frag, const float* a2_frag,
+                                        const float* a1_frag, const float* ln_w, const float* W13T_packed,
+                                        const float* W12T_packed, const float* W11bT_packed, int B, int L, int K,
+                                        float* dz_frag, float* da2_frag, float* da1_rows, float* dP, float* dE_frag,
+                                        float* dln, float* amax3, void* stream) {
+  MPNN_CHECK_ARG(dy_frag && z_frag && a2_frag && a1_frag && ln_w && W13T_packed && W12T_packed && W11bT_packed &&
+                     dz_frag && da2_frag && da1_rows && dP && dE_frag && dln && amax3,
+                 "mpnn_enc_edge_update_bwd: null pointer");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 48,
+                 "mpnn_enc_edge_update_bwd: bad sizes (training path covers K <= 48)");
+  const int N = B * L, KT = (K + 15) / 16;
+  dim3 grid(edge_grid(N, MPNN_BWD_WAVES)), block(MPNN_BWD_WAVES * 64);
+  KT_DISPATCH(KT > 3 ? 3 : KT,
+              hipLaunchKernelGGL((k_edge_update_bwd<(kKT > 3 ? 3 : kKT)>), grid, block, 0, (hipStream_t)stream,
+                                 (const f32x4*)dy_frag, (const f32x4*)z_frag, (const f32x4*)a2_frag,
+                                 (const f32x4*)a1_frag, ln_w, (const h8*)W13T_packed, (const h8*)W12T_packed,
+                                 (const h8*)W11bT_packed, N, (f32x4*)dz_frag, (f32x4*)da2_frag, da1_rows, dP,
+                                 (f32x4*)dE_frag, dln, (unsigned*)amax3));
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax, const float* B_frag, int b_gelu,
+                               int n_nodes, int K, float* dW, float* dbias, void* stream) {
+  MPNN_CHECK_ARG(A && A_absmax && B_frag && dW, "mpnn_edge_wgrad: null pointer");
+  MPNN_CHECK_ARG(n_nodes > 0 && K >= 1 && K <= 48, "mpnn_edge_wgrad: bad sizes (K <= 48)");
+  const int KT = (K + 15) / 16;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  dim3 grid(n_nodes < 2 * cus ? n_nodes : 2 * cus), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const f32x4* Bf = (const f32x4*)B_frag;
+  const unsigned* am = (const unsigned*)A_absmax;
+  if (a_rows) {
+    if (b_gelu) hipLaunchKernelGGL((k_wgrad<true, true>), grid, block, 0, st, A, Bf, am, n_nodes, KT, dW, dbias);
+    else hipLaunchKernelGGL((k_wgrad<true, false>), grid, block, 0, st, A, Bf, am, n_nodes, KT, dW, dbias);
+  } else {
+    if (b_gelu) hipLaunchKernelGGL((k_wgrad<false, true>), grid, block, 0, st, A, Bf, am, n_nodes, KT, dW, dbias);
+    else hipLaunchKernelGGL((k_wgrad<false, false>), grid, block, 0, st, A, Bf, am, n_nodes, KT, dW, dbias);
+  }
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_gather_rows(const float* rows, const int32_t* inv_ptr, const int32_t* inv_row,
+                                const unsigned char* sel, int n_nodes, float* outA, float* outB, void* stream) {
+  MPNN_CHECK_ARG(rows && inv_ptr && inv_row && outA, "mpnn_gather_rows: null pointer");
+  MPNN_CHECK_ARG(n_nodes > 0 && (!sel || outB), "mpnn_gather_rows: a selector needs the second output");
+  hipLaunchKernelGGL(k_gather_rows, dim3((n_nodes + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, inv_ptr, inv_row,
+                     sel, n_nodes, outA, outB);
+  MPNN_LAUNCH_CHECK();
+}

@@ -1,0 +1,48 @@
+// Helpers shared by the forward (mpnn_edge.hip) and backward (mpnn_edge_bwd.hip) per-edge kernels.
+#pragma once
+#include "mpnn_common.h"
+
+// make a (uniform) pointer opaque once per loop iteration: keeps LICM from hoisting hundreds of
+// loop-invariant weight / bias loads out of the persistent loop and pinning them in registers
+#define LAUNDER(p) asm volatile("" : "+s"(p))
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ void lds_fill(h8* dst, const h8* __restrict__ src, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+__device__ __forceinline__ f32x4 row_tile(const float* row, int t) {
+#ifdef MPNN_ABL_NOROW  // timing-only ablation
+  return f32x4{0.1f, 0.2f, 0.3f, 0.4f};
+#endif
+  return *reinterpret_cast<const f32x4*>(row + 16 * t);
+}
+
+constexpr int NKK = MPNN_NT / 2;       // k-steps (32 features) per 128-wide layer
+constexpr int WSPLIT = 8 * NKK * 2 * 64;  // h8 elements of one packed 128x128 matrix (64 KiB)
+
+// ---- host side -------------------------------------------------------------
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+static int edge_grid(int N, int waves) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  const int want = ceil_div(N, waves);
+  return want < cus ? want : cus;
+}
+
+#define KT_DISPATCH(KT, CALL)   \
+  switch (KT) {                 \
+    case 1: { constexpr int kKT = 1; CALL; } break; \
+    case 2: { constexpr int kKT = 2; CALL; } break; \
+    case 3: { constexpr int kKT = 3; CALL; } break; \
+    default: { constexpr int kKT = 4; CALL; } break; \
+  }
+
+static bool mult4(int a, int b = 0, int c = 0, int d = 0, int e = 0, int f = 0) {
+  return ((a | b | c | d | e | f) & 3) == 0;
+}
+

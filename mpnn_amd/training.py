@@ -1,0 +1,306 @@
+"""Training step on the gfx950 kernels (reference: src/mpnn/train.py:63-73 loss, :130-175 step;
+model_utils.py:427-529 forward differentiated by autograd).
+
+What runs where (round 1):
+  * per-edge work (85 % of the FLOPs): message MLPs of the three encoder and three decoder layers and the
+    encoder edge updates -- forward AND backward -- on the hand-written HIP kernels
+    (mpnn_message_train / mpnn_message_bwd / mpnn_enc_edge_update_train / mpnn_enc_edge_update_bwd /
+    mpnn_edge_wgrad / mpnn_gather_rows), wrapped as torch.autograd.Function so the optimizer sees ordinary
+    `.grad`s on the reference-shaped parameters;
+  * neighbour search, backbone atoms, decoding-order ranks: the forward HIP kernels (no gradient flows there);
+  * per-node work (W3, LayerNorm, FFN, projections), the edge featurizer's embedding and the loss: ATen ops on the
+    same device, differentiated by autograd.  These are the remaining 15 %; their fused HIP backward is the next
+    step.
+There is no CPU path: every tensor must live on the ROCm device.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import engine
+from ._lib import call, ptr, stream_ptr
+
+H = 128
+
+
+# ---------------------------------------------------------------------------
+# graph bookkeeping shared by all layers of one step
+# ---------------------------------------------------------------------------
+class Graph:
+    """Neighbour lists of one batch plus the inverse list (edges grouped by the node they gather from)."""
+
+    def __init__(self, E_idx64, E_idx32, mask, edge_mask, K):
+        B, L, _ = E_idx64.shape
+        dev = E_idx64.device
+        self.B, self.L, self.K = B, L, K
+        self.N = B * L
+        self.KT = (K + 15) // 16
+        self.Kp = 16 * self.KT
+        self.E_idx64, self.E_idx32, self.mask, self.edge_mask = E_idx64, E_idx32, mask, edge_mask
+        base = (torch.arange(B, device=dev) * L).view(B, 1, 1)
+        self.dest = (E_idx64 + base).reshape(-1)                      # node each edge gathers from
+        src = torch.arange(self.N, device=dev).view(-1, 1)
+        rows = (src * self.Kp + torch.arange(K, device=dev).view(1, -1)).reshape(-1)
+        self.src = src.expand(-1, K).reshape(-1)
+        self.perm = torch.argsort(self.dest, stable=True)
+        self.inv_row = rows[self.perm].to(torch.int32).contiguous()
+        counts = torch.bincount(self.dest, minlength=self.N)
+        self.inv_ptr = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]).to(torch.int32).contiguous()
+        self.rank = None
+        self.sel = None
+
+    def set_order(self, rank):
+        """rank [N] int32 decoding rank; sel = 1 where the edge read the encoder block (neighbour not yet decoded)."""
+        self.rank = rank
+        r = rank.to(torch.int64)
+        sel = (r[self.src] <= r[self.dest]).to(torch.uint8)
+        self.sel = sel[self.perm].contiguous()
+
+    def frag_numel(self):
+        return self.N * 8 * self.KT * 256
+
+
+def _pack_split(W):
+    """[128,128] fp32 (contiguous) -> f16 hi/lo A-fragment packing."""
+    W = W.detach().contiguous()
+    out = torch.empty(16384, device=W.device, dtype=torch.float32)
+    call("mpnn_pack_linear_split", ptr(W), H, H, H, 0, 0, ptr(out), stream_ptr())
+    return out
+
+
+def _wgrad(A, a_rows, amax, Bfrag, b_gelu, g, want_bias):
+    dW = torch.zeros(H, H, device=A.device, dtype=torch.float32)
+    db = torch.zeros(H, device=A.device, dtype=torch.float32) if want_bias else None
+    call("mpnn_edge_wgrad", ptr(A), int(a_rows), ptr(amax), ptr(Bfrag), int(b_gelu), g.N, g.K, ptr(dW), ptr(db),
+         stream_ptr())
+    return dW, db
+
+
+def _gather(rows, g, sel):
+    outA = torch.empty(g.N, H, device=rows.device, dtype=torch.float32)
+    outB = torch.empty_like(outA) if sel is not None else None
+    call("mpnn_gather_rows", ptr(rows), ptr(g.inv_ptr), ptr(g.inv_row), ptr(sel), g.N, ptr(outA), ptr(outB),
+         stream_ptr())
+    return outA, outB
+
+
+# ---------------------------------------------------------------------------
+# autograd wrappers of the edge kernels
+# ---------------------------------------------------------------------------
+class MessageFn(torch.autograd.Function):
+    """gsum_i = sum_k w_ik gelu(W2 gelu(P_i + s_ik (Row_ik + W1b e_ik)) + b2)   (mpnn_edge.hip k_message)."""
+
+    @staticmethod
+    def forward(ctx, g, dec, hE, P, RowA, RowB, W1b, W2, b2):
+        dev = hE.device
+        P, RowA = P.contiguous(), RowA.contiguous()
+        RowB = RowB.contiguous() if RowB is not None else None
+        gsum = torch.empty(g.N, H, device=dev, dtype=torch.float32)
+        cnt = torch.empty(g.N, device=dev, dtype=torch.float32) if not dec else None
+        a1 = torch.empty(g.frag_numel(), device=dev, dtype=torch.float32)
+        a2 = torch.empty_like(a1)
+        b2c = b2.detach().contiguous()
+        w1p, w2p = _pack_split(W1b), _pack_split(W2)  # named: a temporary's block could be reused before the launch
+        call("mpnn_message_train", int(dec), ptr(hE), ptr(P), ptr(RowA), ptr(RowB), ptr(g.rank) if dec else None,
+             ptr(g.E_idx32), ptr(g.mask), ptr(g.edge_mask), ptr(w1p), ptr(w2p), ptr(b2c),
+             g.B, g.L, g.K, ptr(gsum), ptr(cnt), ptr(a1), ptr(a2), stream_ptr())
+        ctx.g, ctx.dec = g, dec
+        ctx.save_for_backward(hE, a1, a2, W1b, W2)
+        if dec:
+            cnt = torch.full((g.N,), float(g.K), device=dev, dtype=torch.float32)
+        ctx.mark_non_differentiable(cnt)
+        return gsum, cnt
+
+    @staticmethod
+    def backward(ctx, dgsum, _dcnt):
+        g, dec = ctx.g, ctx.dec
+        hE, a1, a2, W1b, W2 = ctx.saved_tensors
+        dev = hE.device
+        dgsum = dgsum.contiguous()
+        da2 = torch.empty_like(a1)
+        rows = torch.empty(g.N * g.Kp, H, device=dev, dtype=torch.float32)
+        dP = torch.empty(g.N, H, device=dev, dtype=torch.float32)
+        dE = torch.empty_like(a1)
+        w2t, w1t = _pack_split(W2.detach().t()), _pack_split(W1b.detach().t())
+        amax = torch.zeros(2, device=dev, dtype=torch.float32)
+        call("mpnn_message_bwd", int(dec), ptr(dgsum), ptr(a1), ptr(a2), ptr(g.E_idx32), ptr(g.mask), ptr(g.edge_mask),
+             ptr(w2t), ptr(w1t), g.B, g.L, g.K, ptr(da2), ptr(rows),
+             ptr(dP), ptr(dE), 0, ptr(amax), stream_ptr())
+        dRowA, dRowB = _gather(rows, g, g.sel if dec else None)
+        dW2, db2 = _wgrad(da2, False, amax[0:1], a1, True, g, True)
+        dW1b, _ = _wgrad(rows, True, amax[1:2], hE, False, g, False)
+        return None, None, dE, dP, dRowA, dRowB, dW1b, dW2, db2
+
+
+class EdgeUpdateFn(torch.autograd.Function):
+    """e' = LN3(e + W13 gelu(W12 gelu(P'_i + Q'_j + W11b e) + b12) + b13)   (mpnn_edge.hip k_enc_edge_update)."""
+
+    @staticmethod
+    def forward(ctx, g, hE, P, Q, W11b, W12, b12, W13, b13, lnw, lnb):
+        dev = hE.device
+        P, Q = P.contiguous(), Q.contiguous()
+        out = torch.empty_like(hE)
+        a1, a2, z = torch.empty_like(hE), torch.empty_like(hE), torch.empty_like(hE)
+        vec = [t.detach().contiguous() for t in (b12, b13, lnw, lnb)]
+        w1p, w2p, w3p = _pack_split(W11b), _pack_split(W12), _pack_split(W13)
+        call("mpnn_enc_edge_update_train", ptr(hE), ptr(P), ptr(Q), ptr(g.E_idx32), ptr(w1p),
+             ptr(w2p), ptr(vec[0]), ptr(w3p), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), g.B, g.L,
+             g.K, ptr(out), ptr(a1), ptr(a2), ptr(z), stream_ptr())
+        ctx.g = g
+        ctx.save_for_backward(hE, a1, a2, z, W11b, W12, W13, lnw)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = ctx.g
+        hE, a1, a2, z, W11b, W12, W13, lnw = ctx.saved_tensors
+        dev = hE.device
+        dy = dy.contiguous()
+        dz, da2, dE = torch.empty_like(hE), torch.empty_like(hE), torch.empty_like(hE)
+        rows = torch.empty(g.N * g.Kp, H, device=dev, dtype=torch.float32)
+        dP = torch.empty(g.N, H, device=dev, dtype=torch.float32)
+        dln = torch.zeros(2 * H, device=dev, dtype=torch.float32)
+        amax = torch.zeros(3, device=dev, dtype=torch.float32)
+        w3t, w2t, w1t = _pack_split(W13.detach().t()), _pack_split(W12.detach().t()), _pack_split(W11b.detach().t())
+        call("mpnn_enc_edge_update_bwd", ptr(dy), ptr(z), ptr(a2), ptr(a1), ptr(lnw.detach().contiguous()),
+             ptr(w3t), ptr(w2t), ptr(w1t),
+             g.B, g.L, g.K, ptr(dz), ptr(da2), ptr(rows), ptr(dP), ptr(dE), ptr(dln), ptr(amax), stream_ptr())
+        dQ, _ = _gather(rows, g, None)
+        dW13, db13 = _wgrad(dz, False, amax[0:1], a2, True, g, True)
+        dW12, db12 = _wgrad(da2, False, amax[1:2], a1, True, g, True)
+        dW11b, _ = _wgrad(rows, True, amax[2:3], hE, False, g, False)
+        return None, dE, dP, dQ, dW11b, dW12, db12, dW13, db13, dln[:H], dln[H:]
+
+
+class FromNaturalFn(torch.autograd.Function):
+    """[N, K, 128] row-major edges -> fragment layout (and back for the gradient)."""
+
+    @staticmethod
+    def forward(ctx, g, h_nat):
+        ctx.g = g
+        return engine.edges_from_natural(h_nat.contiguous(), g.N, g.K)
+
+    @staticmethod
+    def backward(ctx, d_frag):
+        g = ctx.g
+        return None, engine.edges_to_natural(d_frag.contiguous(), g.N, g.K)
+
+
+# ---------------------------------------------------------------------------
+# featurizer embedding (ATen, edge form: O(L K), never L x L)
+# ---------------------------------------------------------------------------
+def _edge_embedding(fm, atoms, g: Graph, residue_idx, chain_labels):
+    """reference :334-358: [positional(16) | 25 or 36 RBF blocks] -> edge_embedding -> norm_edges."""
+    na = 6 if fm.use_virtual_center else 5
+    pos = atoms.view(g.N, 6, 4)[:, :na, :3]
+    nb = pos[g.dest].view(g.N, g.K, 1, na, 3)
+    D = torch.sqrt(((pos.view(g.N, 1, na, 1, 3) - nb) ** 2).sum(-1) + 1e-6)          # [N,K,na(i),na(j)]
+    mu = torch.linspace(2.0, 22.0, fm.num_rbf, device=atoms.device)
+    sigma = (22.0 - 2.0) / fm.num_rbf
+    rbf = torch.exp(-(((D.unsqueeze(-1) - mu) / sigma) ** 2)).reshape(g.N, g.K, na * na * fm.num_rbf)
+    ri, cl = residue_idx.reshape(-1), chain_labels.reshape(-1)
+    m = fm.embeddings.max_relative_feature
+    off = ri[g.src] - ri[g.dest]
+    same = (cl[g.src] == cl[g.dest]).long()
+    d = torch.clip(off + m, 0, 2 * m) * same + (1 - same) * (2 * m + 1)
+    lin = fm.embeddings.linear
+    E_pos = (lin.weight.t()[d] + lin.bias).view(g.N, g.K, -1)
+    E = F.linear(torch.cat([E_pos, rbf], -1), fm.edge_embedding.weight)
+    return F.layer_norm(E, (E.shape[-1],), fm.norm_edges.weight, fm.norm_edges.bias, 1e-5)
+
+
+def _node_tail(lyr, hV, gsum, cnt, mask_col, p_drop, training):
+    """dh = (W3 gsum + cnt b3) / scale; norm1; FFN; norm2; mask   (reference :81-89, :127-138)."""
+    dh = (F.linear(gsum, lyr.W3.weight) + cnt.unsqueeze(-1) * lyr.W3.bias) / lyr.scale
+    hV = lyr.norm1(hV + F.dropout(dh, p_drop, training))
+    ff = F.linear(F.gelu(F.linear(hV, lyr.dense.W_in.weight, lyr.dense.W_in.bias)), lyr.dense.W_out.weight,
+                  lyr.dense.W_out.bias)
+    hV = lyr.norm2(hV + F.dropout(ff, p_drop, training))
+    return mask_col * hV
+
+
+def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order=None,
+                  fix_backbone_noise=None):
+    """ProteinMPNN.forward with autograd (reference :427-529) -> log_probs [B,L,21]."""
+    engine._require_device(X, "X")
+    dev = X.device
+    mask = engine._f32(mask)
+    B, L = mask.shape
+    N = B * L
+    S = engine._i64(S)
+    residue_idx, chain_labels = engine._i64(residue_idx), engine._i64(chain_encoding_all)
+    fm = model.features
+    training = model.training
+    p_drop = float(model.dropout_p)
+    if p_drop > 0 and training and len(model.encoder_layers):
+        raise NotImplementedError("mpnn_amd training: edge-level dropout (EncLayer.dropout3) is not built yet; "
+                                  "construct the model with dropout=0.0")
+    with torch.no_grad():
+        atoms, _, E_idx64, E_idx32, _, edge_mask, K = engine._geometry(fm, X, mask, fix_backbone_noise, training)
+        occ = engine._occupancy(fm, atoms, mask, B, L)
+        g = Graph(E_idx64, E_idx32, mask.reshape(-1).contiguous(), edge_mask, K)
+    if K > 48:
+        raise NotImplementedError("mpnn_amd training kernels cover k_neighbors <= 48")
+    E = _edge_embedding(fm, atoms, g, residue_idx, chain_labels)
+    hE = FromNaturalFn.apply(g, F.linear(E, model.W_e.weight, model.W_e.bias))
+    hV = torch.zeros(N, H, device=dev, dtype=torch.float32)
+    if model.occupancy_mlp is not None and occ is not None:
+        hV = hV + model.occupancy_mlp(occ.view(N, 1))
+    mcol = g.mask.view(N, 1)
+
+    for lyr in model.encoder_layers:
+        W1, W11 = lyr.W1.weight, lyr.W11.weight
+        P, Q = F.linear(hV, W1[:, :H], lyr.W1.bias), F.linear(hV, W1[:, 2 * H:])
+        gsum, cnt = MessageFn.apply(g, False, hE, P, Q, None, W1[:, H:2 * H], lyr.W2.weight, lyr.W2.bias)
+        hV = _node_tail(lyr, hV, gsum, cnt, mcol, p_drop, training)
+        P, Q = F.linear(hV, W11[:, :H], lyr.W11.bias), F.linear(hV, W11[:, 2 * H:])
+        hE = EdgeUpdateFn.apply(g, hE, P, Q, W11[:, H:2 * H], lyr.W12.weight, lyr.W12.bias, lyr.W13.weight,
+                                lyr.W13.bias, lyr.norm3.weight, lyr.norm3.bias)
+
+    if len(model.decoder_layers):
+        with torch.no_grad():
+            cm = engine._f32(chain_M) * mask
+            if fix_order is not None:
+                order = engine._i64(fix_order)
+            else:
+                order = torch.argsort((cm + 0.0001) * torch.abs(torch.randn(cm.shape, device=dev)))
+            rank = torch.zeros(N, device=dev, dtype=torch.int32)
+            call("mpnn_order_rank", ptr(order), B, L, ptr(rank), stream_ptr())
+            g.set_order(rank)
+        hS = model.W_s(S.reshape(-1))
+        hV_enc = hV
+        for lyr in model.decoder_layers:
+            W1 = lyr.W1.weight
+            Pa = F.linear(hV, W1[:, :H], lyr.W1.bias)
+            A = F.linear(hV, W1[:, 3 * H:]) + F.linear(hS, W1[:, 2 * H:3 * H])
+            Benc = F.linear(hV_enc, W1[:, 3 * H:])
+            gsum, cnt = MessageFn.apply(g, True, hE, Pa, A, Benc, W1[:, H:2 * H], lyr.W2.weight, lyr.W2.bias)
+            hV = _node_tail(lyr, hV, gsum, cnt, mcol, p_drop, training)
+    logits = F.linear(hV, model.W_out.weight, model.W_out.bias)
+    return F.log_softmax(logits, dim=-1).view(B, L, -1)
+
+
+def loss_smoothed(S, log_probs, mask, weight=0.1):
+    """Label-smoothed NLL, summed and divided by 2000 (reference train.py:63-73) -> (per-residue loss, scalar)."""
+    n = log_probs.shape[-1]
+    S1 = F.one_hot(S, n).float()
+    S1 = S1 + weight / float(n)
+    S1 = S1 / S1.sum(-1, keepdim=True)
+    loss = -(S1 * log_probs).sum(-1)
+    return loss, torch.sum(loss * mask) / 2000.0
+
+
+def train_step(model, optimizer, batch, world_size=1, fix_order=None, fix_backbone_noise=None):
+    """One optimisation step (reference train.py:130-175): forward, smoothed loss, backward, (all-reduce), step."""
+    from . import distributed
+    X, S, mask, chain_M, residue_idx, chain_enc = batch
+    optimizer.zero_grad(set_to_none=True)
+    log_probs = forward_train(model, X, S, mask, chain_M, residue_idx, chain_enc, fix_order, fix_backbone_noise)
+    mask_for_loss = mask * chain_M
+    _, loss = loss_smoothed(S, log_probs, mask_for_loss)
+    loss.backward()
+    if world_size > 1:
+        distributed.allreduce_gradients(model.parameters(), world_size)
+    optimizer.step()
+    return loss.detach(), log_probs.detach()
