@@ -70,6 +70,57 @@ def cpu_baseline(B_cpu, L, K, iters):
                       f"median of {iters} runs after 1 warm-up, {med * 1e3:.0f} ms each"}
 
 
+def train_leg(a, dev, rank, world, dist, barrier, _lib):
+    """BASELINE configs[2]: full training step (forward, label-smoothed loss, backward, gradient all-reduce over
+    RCCL when world > 1, AdamW) on ~10k-residue batches per rank; reported beside the forward metric."""
+    from mpnn_amd import ProteinMPNN, distributed, training
+    from mpnn_amd.synthetic import synthetic_batch
+
+    B, L, K = a.train_batch, a.length, a.k
+    torch.manual_seed(1234)
+    model = ProteinMPNN(k_neighbors=K, augment_eps=0.0, dropout=0.0).train().to(dev)
+    if world > 1:
+        distributed.broadcast_parameters(model.parameters())
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2)
+    b = synthetic_batch(B, L, seed=2000 + rank, device=dev)
+    batch = (b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
+    steps, warm = max(3, min(a.steps, 10)), 2
+
+    def step():
+        return training.train_step(model, opt, batch, world_size=world, fix_order=b["fix_order"])
+
+    for _ in range(warm):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(loss)
+    prof = {}
+    _lib.set_profiler(prof)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    _lib.set_profiler(None)
+    kern = {n: round(sum(e0.elapsed_time(e1) for e0, e1 in evs) / 3, 3) for n, evs in sorted(prof.items())}
+    hip_ms = sum(kern.values())
+    return {"metric": "residues/sec (train step: fwd + bwd + AdamW) at L=512,k=48",
+            "value": round(B * L * world * steps / elapsed, 1), "unit": "residues/s", "n_gpus": world, "steps": steps,
+            "warmup": warm, "ms_per_step": round(elapsed / steps * 1e3, 3), "scaling": "weak",
+            "config": {"workload": f"BASELINE configs[2]: {B} x L={L} = {B * L} residues per rank, k={K}, dropout 0, "
+                                   "AdamW, one flat gradient all-reduce per step", "global_batch": B * world},
+            "final_loss": round(float(loss), 6),
+            "hip_kernels_ms_per_step": kern, "hip_kernels_total_ms": round(hip_ms, 3),
+            "note": "per-edge forward/backward/weight-gradient kernels are HIP; per-node ops, featurizer embedding "
+                    "and optimizer run as ATen ops this round (remaining time = ms_per_step - hip_kernels_total_ms)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +130,8 @@ def main():
     ap.add_argument("--length", type=int, default=512)
     ap.add_argument("--k", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-batch", type=int, default=20,
+                    help="proteins per rank in the training leg (BASELINE configs[2]: ~10k-residue batches); 0 = skip")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -163,6 +216,10 @@ def main():
                             "The kernel is VALU-issue bound (GELU + f16 splitting do not co-issue with MFMA here), "
                             "see DESIGN.md section 4"}
 
+    train = None
+    if a.train_batch > 0:
+        train = train_leg(a, dev, rank, world, dist, barrier, _lib)
+
     if rank == 0:
         total_res = B * L * world * a.steps
         value = total_res / elapsed
@@ -178,6 +235,8 @@ def main():
             "roofline": roofline,
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(per_kernel.items())},
         }
+        if train is not None:
+            line["train_step"] = train
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(2, L, K, iters=3)
         print(json.dumps(line), flush=True)

@@ -205,7 +205,9 @@ def _edge_embedding(fm, atoms, g: Graph, residue_idx, chain_labels):
     same = (cl[g.src] == cl[g.dest]).long()
     d = torch.clip(off + m, 0, 2 * m) * same + (1 - same) * (2 * m + 1)
     lin = fm.embeddings.linear
-    E_pos = (lin.weight.t()[d] + lin.bias).view(g.N, g.K, -1)
+    # one-hot -> linear exactly as the reference writes it (:170-176): its backward is a GEMM, where an index lookup's
+    # backward is a 491k-row scatter into 66 rows (measured 38 ms per step at 20 x 512)
+    E_pos = F.linear(F.one_hot(d, 2 * m + 2).to(torch.float32), lin.weight, lin.bias).view(g.N, g.K, -1)
     E = F.linear(torch.cat([E_pos, rbf], -1), fm.edge_embedding.weight)
     return F.layer_norm(E, (E.shape[-1],), fm.norm_edges.weight, fm.norm_edges.bias, 1e-5)
 
