@@ -4,7 +4,7 @@ ARCH  ?= gfx950
 CSRC  := mpnn_amd/csrc
 OUT   := mpnn_amd/libmpnn_hip.so
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wno-unused-result $(EXTRA)
-OBJS  := $(CSRC)/mpnn_featurizer.o $(CSRC)/mpnn_edge.o $(CSRC)/mpnn_edge_bwd.o $(CSRC)/mpnn_node.o $(CSRC)/mpnn_abi.o
+OBJS  := $(CSRC)/mpnn_featurizer.o $(CSRC)/mpnn_edge.o $(CSRC)/mpnn_edge_bwd.o $(CSRC)/mpnn_node.o $(CSRC)/mpnn_node_bwd.o $(CSRC)/mpnn_abi.o
 
 all: $(OUT)
 
@@ -30,4 +30,7 @@ clean:
 .PHONY: all clean
 
 $(CSRC)/mpnn_node.o: $(CSRC)/mpnn_node.hip $(CSRC)/mpnn_common.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(CSRC)/mpnn_node_bwd.o: $(CSRC)/mpnn_node_bwd.hip $(CSRC)/mpnn_common.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

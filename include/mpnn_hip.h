@@ -175,6 +175,33 @@ int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax, const flo
 int mpnn_gather_rows(const float* rows, const int32_t* inv_ptr, const int32_t* inv_row, const unsigned char* sel,
                      int n_nodes, float* outA, float* outB, void* stream);
 
+/* Training forward of mpnn_edge_features: also stores the pre-LayerNorm embedding E0 and E = norm_edges(E0), both in
+ * the fragment layout, for mpnn_edge_features_bwd / mpnn_edge_wgrad (:334-358, :464). */
+int mpnn_edge_features_train(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
+                             const int64_t* chain_labels, const float* pos_table, const float* rbf_mu,
+                             const float* Wemb_packed, const float* ln_w, const float* ln_b, const float* We_packed,
+                             const float* We_bias, int B, int L, int K, int n_atoms, float* E0_frag, float* E_frag,
+                             float* hE_frag, void* stream);
+
+/* Featurizer backward: dE = W_e^T dhE0, dE0 = LayerNorm'(dE; E0).  WeT_packed = mpnn_pack_linear_split(W_e^T).
+ * dln[0:128] += d norm_edges.weight, dln[128:256] += d norm_edges.bias; amax2 (zeroed) <- max |dhE0|, max |dE0|. */
+int mpnn_edge_features_bwd(const float* dhE_frag, const float* E0_frag, const float* ln_w, const float* WeT_packed,
+                           int B, int L, int K, float* dE0_frag, float* dln, float* amax2, void* stream);
+
+/* The edge_embedding layer's raw inputs in the fragment layout, 128 features per chunk, chunks back to back:
+ * feature 16 p + r (p < n_atoms^2) = RBF r of atom pair p (:334-347); features 16 n_atoms^2 + d = one-hot of the
+ * relative-position bucket d in [0, 66) (:349-356); zero padding up to ceil((n_atoms^2 + 5) / 8) chunks.
+ * Contracted with dE0 by mpnn_edge_wgrad they give the edge_embedding / positional-linear weight gradients. */
+int mpnn_feature_chunks(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
+                        const int64_t* chain_labels, const float* rbf_mu, int B, int L, int K, int n_atoms,
+                        float* chunks_frag, void* stream);
+
+/* Weight / bias gradient of an nn.Linear over per-residue rows (autograd of the node-level linears, :78-93, :151-155):
+ * dW[o][i] += sum_n dY[n][o] X[n][i]  (row strides ldy, ldx, ldw; fp32 products), dbias[o] += sum_n dY[n][o].
+ * Accumulates with atomics: zero dW / dbias first.  dbias may be NULL. */
+int mpnn_node_wgrad(const float* dY, int ldy, int out_f, const float* X, int ldx, int in_f, int n_rows, float* dW,
+                    int ldw, float* dbias, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

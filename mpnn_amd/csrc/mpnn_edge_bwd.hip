@@ -185,45 +185,13 @@ k_message_bwd(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, con
   if (threadIdx.x < 2) atomicMax(amax + threadIdx.x, amax_l[threadIdx.x]);
 }
 
-// ---------------------------------------------------------------------------
-// encoder edge-update backward.  dE may alias dy (each wave reads its residue's dy before writing).
-// LayerNorm parameter gradients are reduced per workgroup in LDS, then added to dln[0:128] (weight) and
-// dln[128:256] (bias) with one atomic per entry and workgroup.
-// ---------------------------------------------------------------------------
+// LayerNorm backward over each column's 128 features, in registers.
+//   in : x = z (pre-LayerNorm input), d = dy;  out: d = dz, x = xhat (scratch)
+//   the weight / bias gradients sum_edges dy*xhat, sum_edges dy are added to lnacc[0:128], lnacc[128:256] (LDS)
 template <int KT>
-__global__ void __launch_bounds__(MPNN_BWD_WAVES * 64)
-k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __restrict__ a2,
-                  const f32x4* __restrict__ a1, const float* __restrict__ ln_w, const h8* __restrict__ W13T,
-                  const h8* __restrict__ W12T, const h8* __restrict__ W11bT, int N, f32x4* __restrict__ dz_out,
-                  f32x4* __restrict__ da2_out, float* __restrict__ da1_nat, float* __restrict__ dP, f32x4* dE,
-                  float* __restrict__ dln, unsigned* __restrict__ amax) {
-  __shared__ h8 lds[2 * WSPLIT];
-  __shared__ float lnacc[2 * MPNN_H];
-  __shared__ unsigned amax_l[3];
-  if (threadIdx.x < 3) amax_l[threadIdx.x] = 0u;
-  lds_fill(lds, W13T, WSPLIT);
-  lds_fill(lds + WSPLIT, W12T, WSPLIT);
-  if (threadIdx.x < 2 * MPNN_H) lnacc[threadIdx.x] = 0.f;
-  __syncthreads();
-  const h8* W3s = lds;
-  const h8* W2s = lds + WSPLIT;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void tile_layernorm_bwd(f32x4 (&x)[MPNN_NT][KT], f32x4 (&d)[MPNN_NT][KT],
+                                                   const float* __restrict__ ln_w, float* lnacc, int lane) {
   const int g = lane >> 4, col = lane & 15;
-  constexpr int Kp = KT * 16;
-  const int stride = gridDim.x * MPNN_BWD_WAVES;
-  for (int node = blockIdx.x * MPNN_BWD_WAVES + wave; node < N; node += stride) {
-    LAUNDER(ln_w);
-    const h8* W1u = W11bT;
-    LAUNDER(W1u);
-    const size_t off = (size_t)node * (MPNN_NT * KT * 64) + lane;
-    f32x4 x[MPNN_NT][KT], d[MPNN_NT][KT];
-#pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t)
-#pragma unroll
-      for (int c = 0; c < KT; ++c) {
-        x[t][c] = z[off + (t * KT + c) * 64];
-        d[t][c] = dy[off + (t * KT + c) * 64];
-      }
     // x <- xhat
     float rstd[KT];
 #pragma unroll
@@ -278,9 +246,54 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t) {
         d[t][c] = (d[t][c] - m1 - x[t][c] * m2) * rstd[c];
-        dz_out[off + (t * KT + c) * 64] = d[t][c];
       }
     }
+}
+
+// ---------------------------------------------------------------------------
+// encoder edge-update backward.  dE may alias dy (each wave reads its residue's dy before writing).
+// LayerNorm parameter gradients are reduced per workgroup in LDS, then added to dln[0:128] (weight) and
+// dln[128:256] (bias) with one atomic per entry and workgroup.
+// ---------------------------------------------------------------------------
+template <int KT>
+__global__ void __launch_bounds__(MPNN_BWD_WAVES * 64)
+k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __restrict__ a2,
+                  const f32x4* __restrict__ a1, const float* __restrict__ ln_w, const h8* __restrict__ W13T,
+                  const h8* __restrict__ W12T, const h8* __restrict__ W11bT, int N, f32x4* __restrict__ dz_out,
+                  f32x4* __restrict__ da2_out, float* __restrict__ da1_nat, float* __restrict__ dP, f32x4* dE,
+                  float* __restrict__ dln, unsigned* __restrict__ amax) {
+  __shared__ h8 lds[2 * WSPLIT];
+  __shared__ float lnacc[2 * MPNN_H];
+  __shared__ unsigned amax_l[3];
+  if (threadIdx.x < 3) amax_l[threadIdx.x] = 0u;
+  lds_fill(lds, W13T, WSPLIT);
+  lds_fill(lds + WSPLIT, W12T, WSPLIT);
+  if (threadIdx.x < 2 * MPNN_H) lnacc[threadIdx.x] = 0.f;
+  __syncthreads();
+  const h8* W3s = lds;
+  const h8* W2s = lds + WSPLIT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  constexpr int Kp = KT * 16;
+  const int stride = gridDim.x * MPNN_BWD_WAVES;
+  for (int node = blockIdx.x * MPNN_BWD_WAVES + wave; node < N; node += stride) {
+    LAUNDER(ln_w);
+    const h8* W1u = W11bT;
+    LAUNDER(W1u);
+    const size_t off = (size_t)node * (MPNN_NT * KT * 64) + lane;
+    f32x4 x[MPNN_NT][KT], d[MPNN_NT][KT];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        x[t][c] = z[off + (t * KT + c) * 64];
+        d[t][c] = dy[off + (t * KT + c) * 64];
+      }
+    tile_layernorm_bwd<KT>(x, d, ln_w, lnacc, lane);
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) dz_out[off + (t * KT + c) * 64] = d[t][c];
     BFrag db[NKK][KT];
     float un = grad_to_bfrag<KT>(d, db, &amax_l[0]);
     // ---- through W13, gelu'(a2)
@@ -316,6 +329,58 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
   __syncthreads();
   if (threadIdx.x < 2 * MPNN_H) unsafeAtomicAdd(dln + threadIdx.x, lnacc[threadIdx.x]);
   if (threadIdx.x < 3) atomicMax(amax + threadIdx.x, amax_l[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------
+// featurizer backward (reference :357-358 norm_edges(edge_embedding(.)) followed by W_e, :464):
+//   dE = W_e^T dhE0;   dE0 = LayerNorm'(dE; E0)   ->  dE0 (fragment layout, feeds mpnn_edge_wgrad against the
+//   feature chunks), norm_edges weight / bias gradients, and the magnitudes the weight-gradient kernel scales by
+//   (amax[0] = max |dhE0|, amax[1] = max |dE0|).
+// ---------------------------------------------------------------------------
+template <int KT>
+__global__ void __launch_bounds__(MPNN_BWD_WAVES * 64)
+k_features_bwd(const f32x4* __restrict__ dy, const f32x4* __restrict__ E0, const float* __restrict__ ln_w,
+               const h8* __restrict__ WeT, int N, f32x4* __restrict__ dE0, float* __restrict__ dln,
+               unsigned* __restrict__ amax) {
+  __shared__ h8 lds[WSPLIT];
+  __shared__ float lnacc[2 * MPNN_H];
+  __shared__ unsigned amax_l[2];
+  lds_fill(lds, WeT, WSPLIT);
+  if (threadIdx.x < 2 * MPNN_H) lnacc[threadIdx.x] = 0.f;
+  if (threadIdx.x < 2) amax_l[threadIdx.x] = 0u;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int stride = gridDim.x * MPNN_BWD_WAVES;
+  for (int node = blockIdx.x * MPNN_BWD_WAVES + wave; node < N; node += stride) {
+    LAUNDER(ln_w);
+    const size_t off = (size_t)node * (MPNN_NT * KT * 64) + lane;
+    f32x4 x[MPNN_NT][KT], d[MPNN_NT][KT];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) x[t][c] = dy[off + (t * KT + c) * 64];
+    BFrag db[NKK][KT];
+    const float un = grad_to_bfrag<KT>(x, db, &amax_l[0]);
+    zero_tile<KT>(d);
+    split_gemm<KT, NKK, 0, MPNN_NT>(lds, lane, db, d);
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        d[t][c] *= un;
+        x[t][c] = E0[off + (t * KT + c) * 64];
+      }
+    tile_layernorm_bwd<KT>(x, d, ln_w, lnacc, lane);
+    const unsigned mb = tile_absmax_bits<KT>(d);
+    if (lane == 0) atomicMax(&amax_l[1], mb);
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) dE0[off + (t * KT + c) * 64] = d[t][c];
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * MPNN_H) unsafeAtomicAdd(dln + threadIdx.x, lnacc[threadIdx.x]);
+  if (threadIdx.x < 2) atomicMax(amax + threadIdx.x, amax_l[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------
@@ -525,5 +590,20 @@ extern "C" int mpnn_gather_rows(const float* rows, const int32_t* inv_ptr, const
   MPNN_CHECK_ARG(n_nodes > 0 && (!sel || outB), "mpnn_gather_rows: a selector needs the second output");
   hipLaunchKernelGGL(k_gather_rows, dim3((n_nodes + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, inv_ptr, inv_row,
                      sel, n_nodes, outA, outB);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_edge_features_bwd(const float* dhE_frag, const float* E0_frag, const float* ln_w,
+                                      const float* WeT_packed, int B, int L, int K, float* dE0_frag, float* dln,
+                                      float* amax2, void* stream) {
+  MPNN_CHECK_ARG(dhE_frag && E0_frag && ln_w && WeT_packed && dE0_frag && dln && amax2,
+                 "mpnn_edge_features_bwd: null pointer");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 48, "mpnn_edge_features_bwd: bad sizes (K <= 48)");
+  const int N = B * L, KT = (K + 15) / 16;
+  dim3 grid(edge_grid(N, MPNN_BWD_WAVES)), block(MPNN_BWD_WAVES * 64);
+  KT_DISPATCH(KT > 3 ? 3 : KT,
+              hipLaunchKernelGGL((k_features_bwd<(kKT > 3 ? 3 : kKT)>), grid, block, 0, (hipStream_t)stream,
+                                 (const f32x4*)dhE_frag, (const f32x4*)E0_frag, ln_w, (const h8*)WeT_packed, N,
+                                 (f32x4*)dE0_frag, dln, (unsigned*)amax2));
   MPNN_LAUNCH_CHECK();
 }

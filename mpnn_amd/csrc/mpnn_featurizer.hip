@@ -268,13 +268,14 @@ __global__ void k_pos_table(const float* __restrict__ W, const float* __restrict
 // Both weights stream from L2 as A fragments; outputs: hE in fragment layout and, optionally, E in the
 // reference's natural [N,K,128] layout.
 // ---------------------------------------------------------------------------
-template <int KT, int A>
+template <int KT, int A, bool SAVE>
 __global__ void __launch_bounds__(256, 2)
 k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, const long long* __restrict__ residue_idx,
                 const long long* __restrict__ chain_labels, const float* __restrict__ pos_table,
                 const float* __restrict__ rbf_mu, const h8* __restrict__ Wemb, const float* __restrict__ ln_w,
                 const float* __restrict__ ln_b, const h8* __restrict__ We, const float* __restrict__ be, int N,
-                int L, int K, float* __restrict__ E_nat, float* __restrict__ hE) {
+                int L, int K, float* __restrict__ E_nat, float* __restrict__ hE, f32x4* __restrict__ E0_frag,
+                f32x4* __restrict__ E_frag) {
   constexpr int NT_IN = A * A + 1;            // feature tiles: pairs, then positional
   constexpr int NKK_IN = (NT_IN + 1) / 2;     // k-steps of 32 features
   constexpr int D = 3;
@@ -354,8 +355,21 @@ k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, 
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  const size_t foff = (size_t)node * (MPNN_NT * KT * 64) + lane;
+  if (SAVE) {  // training: pre-LayerNorm embedding for the backward kernel
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) E0_frag[foff + (t * KT + c) * 64] = acc[t][c];
+  }
   // ---- LayerNorm over features (norm_edges)
   tile_layernorm<KT>(acc, ln_w, ln_b, lane);
+  if (SAVE) {
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) E_frag[foff + (t * KT + c) * 64] = acc[t][c];
+  }
   if (E_nat) {
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
@@ -508,14 +522,20 @@ template <int KT>
 static int launch_edge_features(int A, const float* atoms, const int* E_idx, const long long* ridx,
                                 const long long* chain, const float* pos_table, const float* rbf_mu,
                                 const float* Wemb, const float* ln_w, const float* ln_b, const float* We,
-                                const float* be, int N, int L, int K, float* E_nat, float* hE, hipStream_t s) {
+                                const float* be, int N, int L, int K, float* E_nat, float* hE, hipStream_t s,
+                                float* E0_frag = nullptr, float* E_frag = nullptr) {
   dim3 grid(ceil_div(N, 4)), block(256);
-  if (A == 5)
-    hipLaunchKernelGGL((k_edge_features<KT, 5>), grid, block, 0, s, atoms, E_idx, ridx, chain, pos_table, rbf_mu,
-                       (const h8*)Wemb, ln_w, ln_b, (const h8*)We, be, N, L, K, E_nat, hE);
-  else
-    hipLaunchKernelGGL((k_edge_features<KT, 6>), grid, block, 0, s, atoms, E_idx, ridx, chain, pos_table, rbf_mu,
-                       (const h8*)Wemb, ln_w, ln_b, (const h8*)We, be, N, L, K, E_nat, hE);
+#define MPNN_FEAT_LAUNCH(AA, SV)                                                                                  \
+  hipLaunchKernelGGL((k_edge_features<KT, AA, SV>), grid, block, 0, s, atoms, E_idx, ridx, chain, pos_table, rbf_mu, \
+                     (const h8*)Wemb, ln_w, ln_b, (const h8*)We, be, N, L, K, E_nat, hE, (f32x4*)E0_frag,          \
+                     (f32x4*)E_frag)
+  const bool save = E0_frag != nullptr;
+  if (A == 5) {
+    if (save) MPNN_FEAT_LAUNCH(5, true); else MPNN_FEAT_LAUNCH(5, false);
+  } else {
+    if (save) MPNN_FEAT_LAUNCH(6, true); else MPNN_FEAT_LAUNCH(6, false);
+  }
+#undef MPNN_FEAT_LAUNCH
   MPNN_LAUNCH_CHECK();
 }
 
@@ -538,6 +558,97 @@ extern "C" int mpnn_edge_features(const float* atoms, const int32_t* E_idx32, co
     case 3: return launch_edge_features<3>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, E_natural, hE_frag, s);
     default: return launch_edge_features<4>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, E_natural, hE_frag, s);
   }
+}
+
+extern "C" int mpnn_edge_features_train(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
+                                        const int64_t* chain_labels, const float* pos_table, const float* rbf_mu,
+                                        const float* Wemb_packed, const float* ln_w, const float* ln_b,
+                                        const float* We_packed, const float* We_bias, int B, int L, int K, int n_atoms,
+                                        float* E0_frag, float* E_frag, float* hE_frag, void* stream) {
+  MPNN_CHECK_ARG(atoms && E_idx32 && residue_idx && chain_labels && pos_table && rbf_mu && Wemb_packed && ln_w &&
+                     ln_b && We_packed && We_bias && hE_frag && E0_frag && E_frag,
+                 "mpnn_edge_features_train: null pointer");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 48, "mpnn_edge_features_train: need 1 <= K <= 48");
+  MPNN_CHECK_ARG(n_atoms == 5 || n_atoms == 6, "mpnn_edge_features_train: n_atoms must be 5 or 6");
+  const int KT = (K + 15) / 16, N = B * L;
+  hipStream_t s = (hipStream_t)stream;
+  const long long *ri = (const long long*)residue_idx, *cl = (const long long*)chain_labels;
+  switch (KT) {
+    case 1: return launch_edge_features<1>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag);
+    case 2: return launch_edge_features<2>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag);
+    default: return launch_edge_features<3>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Training: the featurizer's raw inputs, materialised once per backward pass in the fragment layout so that the
+// generic per-edge weight-gradient kernel (mpnn_edge_wgrad) can contract them with dE0:
+//   feature tile T < A*A          : the 16 RBFs of atom pair T                       (reference :334-347)
+//   feature tiles A*A .. A*A + 4  : one-hot of the relative-position bucket d (66)    (reference :349-356, :170-176)
+// tile T lives in chunk T / 8 (a chunk = 128 features = one hE-shaped array), chunks stored back to back.
+// ---------------------------------------------------------------------------
+template <int A>
+__global__ void __launch_bounds__(256)
+k_feature_chunks(const float* __restrict__ atoms, const int* __restrict__ E_idx, const long long* __restrict__ residue_idx,
+                 const long long* __restrict__ chain_labels, const float* __restrict__ rbf_mu, int N, int L, int KT,
+                 f32x4* __restrict__ F) {
+  constexpr int NTILE = A * A + 5;
+  constexpr int NCH = (NTILE + 7) / 8;
+  const int lane = threadIdx.x & 63;
+  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (node >= N) return;
+  const int g = lane >> 4, col = lane & 15;
+  const int b = node / L, Kp = KT * 16;
+  float mu[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) mu[r] = rbf_mu[4 * g + r];
+  const f32x4* atom_i = reinterpret_cast<const f32x4*>(atoms + (size_t)node * 24);
+  const long long ri = residue_idx[node], ci = chain_labels[node];
+  const size_t chunk = (size_t)N * MPNN_NT * KT * 64;
+  for (int c = 0; c < KT; ++c) {
+    const int jn = b * L + E_idx[(size_t)node * Kp + 16 * c + col];
+    const f32x4* atom_j = reinterpret_cast<const f32x4*>(atoms + (size_t)jn * 24);
+    long long d = ri - residue_idx[jn] + 32;
+    d = d < 0 ? 0 : (d > 64 ? 64 : d);
+    if (ci != chain_labels[jn]) d = 65;
+#pragma unroll
+    for (int T = 0; T < NCH * 8; ++T) {
+      f32x4 x = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (T < A * A) {
+        const f32x4 Ai = atom_i[T / A], Bj = atom_j[T % A];
+        const float dx = Ai.x - Bj.x, dy = Ai.y - Bj.y, dz = Ai.z - Bj.z;
+        const float dist = sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float z = (dist - mu[r]) * 0.96089792702915982f;
+          x[r] = __builtin_amdgcn_exp2f(-(z * z));
+        }
+      } else if (T < NTILE) {
+        const int f0 = 16 * (T - A * A) + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = (f0 + r == (int)d) ? 1.0f : 0.0f;
+      }
+      F[(size_t)(T / 8) * chunk + ((size_t)node * MPNN_NT + (T % 8)) * KT * 64 + c * 64 + lane] = x;
+    }
+  }
+}
+
+extern "C" int mpnn_feature_chunks(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
+                                   const int64_t* chain_labels, const float* rbf_mu, int B, int L, int K, int n_atoms,
+                                   float* chunks_frag, void* stream) {
+  MPNN_CHECK_ARG(atoms && E_idx32 && residue_idx && chain_labels && rbf_mu && chunks_frag,
+                 "mpnn_feature_chunks: null pointer");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && (n_atoms == 5 || n_atoms == 6), "mpnn_feature_chunks: bad sizes");
+  const int KT = (K + 15) / 16, N = B * L;
+  dim3 grid(ceil_div(N, 4)), block(256);
+  const long long *ri = (const long long*)residue_idx, *cl = (const long long*)chain_labels;
+  if (n_atoms == 5)
+    hipLaunchKernelGGL(k_feature_chunks<5>, grid, block, 0, (hipStream_t)stream, atoms, E_idx32, ri, cl, rbf_mu, N, L, KT,
+                       (f32x4*)chunks_frag);
+  else
+    hipLaunchKernelGGL(k_feature_chunks<6>, grid, block, 0, (hipStream_t)stream, atoms, E_idx32, ri, cl, rbf_mu, N, L, KT,
+                       (f32x4*)chunks_frag);
+  MPNN_LAUNCH_CHECK();
 }
 
 extern "C" int mpnn_edges_to_natural(const float* hE_frag, int n_nodes, int K, float* natural, void* stream) {

@@ -8,9 +8,10 @@ What runs where (round 1):
     mpnn_edge_wgrad / mpnn_gather_rows), wrapped as torch.autograd.Function so the optimizer sees ordinary
     `.grad`s on the reference-shaped parameters;
   * neighbour search, backbone atoms, decoding-order ranks: the forward HIP kernels (no gradient flows there);
-  * per-node work (W3, LayerNorm, FFN, projections), the edge featurizer's embedding and the loss: ATen ops on the
-    same device, differentiated by autograd.  These are the remaining 15 %; their fused HIP backward is the next
-    step.
+  * the edge featurizer (RBF / positional embedding -> edge_embedding -> norm_edges -> W_e): forward and backward on
+    HIP kernels too (mpnn_edge_features_train / mpnn_edge_features_bwd / mpnn_feature_chunks + mpnn_edge_wgrad);
+  * per-node work (W3, LayerNorm, FFN, projections) and the loss: ATen ops on the same device, differentiated by
+    autograd, with the node-level weight gradients on mpnn_node_wgrad.  A fused HIP node backward is the next step.
 There is no CPU path: every tensor must live on the ROCm device.
 """
 from __future__ import annotations
@@ -85,6 +86,41 @@ def _gather(rows, g, sel):
     return outA, outB
 
 
+class LinearFn(torch.autograd.Function):
+    """F.linear on [rows, in] whose weight / bias gradients come from mpnn_node_wgrad (split-K fp32 MFMA + atomics):
+    the library GEMM for this 'tiny output, 10^4-long reduction' shape takes 91 us per call."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return F.linear(x, W, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        x = x.contiguous()
+        dx = dy @ W if ctx.needs_input_grad[0] else None
+        dW = torch.zeros(W.shape, device=dy.device, dtype=torch.float32)
+        db = torch.zeros(W.shape[0], device=dy.device, dtype=torch.float32) if ctx.has_bias else None
+        call("mpnn_node_wgrad", ptr(dy), dy.shape[1], dy.shape[1], ptr(x), x.shape[1], x.shape[1], dy.shape[0], ptr(dW),
+             dW.shape[1], ptr(db), stream_ptr())
+        return dx, dW, db
+
+
+def linear(x, W, b=None):
+    return LinearFn.apply(x, W, b)
+
+
+class GradSlot:
+    """Shared gradient buffer of one edge tensor hE_l.  Its consumers' backward kernels accumulate in place; the first
+    one hands the buffer to autograd, the others return None (autograd runs the producer only after all of them)."""
+
+    def __init__(self):
+        self.buf = None
+
+
 # ---------------------------------------------------------------------------
 # autograd wrappers of the edge kernels
 # ---------------------------------------------------------------------------
@@ -92,7 +128,7 @@ class MessageFn(torch.autograd.Function):
     """gsum_i = sum_k w_ik gelu(W2 gelu(P_i + s_ik (Row_ik + W1b e_ik)) + b2)   (mpnn_edge.hip k_message)."""
 
     @staticmethod
-    def forward(ctx, g, dec, hE, P, RowA, RowB, W1b, W2, b2):
+    def forward(ctx, g, slot, dec, hE, P, RowA, RowB, W1b, W2, b2):
         dev = hE.device
         P, RowA = P.contiguous(), RowA.contiguous()
         RowB = RowB.contiguous() if RowB is not None else None
@@ -105,7 +141,7 @@ class MessageFn(torch.autograd.Function):
         call("mpnn_message_train", int(dec), ptr(hE), ptr(P), ptr(RowA), ptr(RowB), ptr(g.rank) if dec else None,
              ptr(g.E_idx32), ptr(g.mask), ptr(g.edge_mask), ptr(w1p), ptr(w2p), ptr(b2c),
              g.B, g.L, g.K, ptr(gsum), ptr(cnt), ptr(a1), ptr(a2), stream_ptr())
-        ctx.g, ctx.dec = g, dec
+        ctx.g, ctx.dec, ctx.slot = g, dec, slot
         ctx.save_for_backward(hE, a1, a2, W1b, W2)
         if dec:
             cnt = torch.full((g.N,), float(g.K), device=dev, dtype=torch.float32)
@@ -121,23 +157,27 @@ class MessageFn(torch.autograd.Function):
         da2 = torch.empty_like(a1)
         rows = torch.empty(g.N * g.Kp, H, device=dev, dtype=torch.float32)
         dP = torch.empty(g.N, H, device=dev, dtype=torch.float32)
-        dE = torch.empty_like(a1)
+        slot = ctx.slot
+        first = slot.buf is None
+        if first:
+            slot.buf = torch.empty_like(a1)
+        dE = slot.buf
         w2t, w1t = _pack_split(W2.detach().t()), _pack_split(W1b.detach().t())
         amax = torch.zeros(2, device=dev, dtype=torch.float32)
         call("mpnn_message_bwd", int(dec), ptr(dgsum), ptr(a1), ptr(a2), ptr(g.E_idx32), ptr(g.mask), ptr(g.edge_mask),
              ptr(w2t), ptr(w1t), g.B, g.L, g.K, ptr(da2), ptr(rows),
-             ptr(dP), ptr(dE), 0, ptr(amax), stream_ptr())
+             ptr(dP), ptr(dE), 0 if first else 1, ptr(amax), stream_ptr())
         dRowA, dRowB = _gather(rows, g, g.sel if dec else None)
         dW2, db2 = _wgrad(da2, False, amax[0:1], a1, True, g, True)
         dW1b, _ = _wgrad(rows, True, amax[1:2], hE, False, g, False)
-        return None, None, dE, dP, dRowA, dRowB, dW1b, dW2, db2
+        return None, None, None, dE if first else None, dP, dRowA, dRowB, dW1b, dW2, db2
 
 
 class EdgeUpdateFn(torch.autograd.Function):
     """e' = LN3(e + W13 gelu(W12 gelu(P'_i + Q'_j + W11b e) + b12) + b13)   (mpnn_edge.hip k_enc_edge_update)."""
 
     @staticmethod
-    def forward(ctx, g, hE, P, Q, W11b, W12, b12, W13, b13, lnw, lnb):
+    def forward(ctx, g, slot, hE, P, Q, W11b, W12, b12, W13, b13, lnw, lnb):
         dev = hE.device
         P, Q = P.contiguous(), Q.contiguous()
         out = torch.empty_like(hE)
@@ -147,7 +187,7 @@ class EdgeUpdateFn(torch.autograd.Function):
         call("mpnn_enc_edge_update_train", ptr(hE), ptr(P), ptr(Q), ptr(g.E_idx32), ptr(w1p),
              ptr(w2p), ptr(vec[0]), ptr(w3p), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), g.B, g.L,
              g.K, ptr(out), ptr(a1), ptr(a2), ptr(z), stream_ptr())
-        ctx.g = g
+        ctx.g, ctx.slot = g, slot
         ctx.save_for_backward(hE, a1, a2, z, W11b, W12, W13, lnw)
         return out
 
@@ -157,7 +197,9 @@ class EdgeUpdateFn(torch.autograd.Function):
         hE, a1, a2, z, W11b, W12, W13, lnw = ctx.saved_tensors
         dev = hE.device
         dy = dy.contiguous()
+        assert ctx.slot.buf is None, "the edge update is the first consumer of its input to run backward"
         dz, da2, dE = torch.empty_like(hE), torch.empty_like(hE), torch.empty_like(hE)
+        ctx.slot.buf = dE
         rows = torch.empty(g.N * g.Kp, H, device=dev, dtype=torch.float32)
         dP = torch.empty(g.N, H, device=dev, dtype=torch.float32)
         dln = torch.zeros(2 * H, device=dev, dtype=torch.float32)
@@ -170,7 +212,7 @@ class EdgeUpdateFn(torch.autograd.Function):
         dW13, db13 = _wgrad(dz, False, amax[0:1], a2, True, g, True)
         dW12, db12 = _wgrad(da2, False, amax[1:2], a1, True, g, True)
         dW11b, _ = _wgrad(rows, True, amax[2:3], hE, False, g, False)
-        return None, dE, dP, dQ, dW11b, dW12, db12, dW13, db13, dln[:H], dln[H:]
+        return None, None, dE, dP, dQ, dW11b, dW12, db12, dW13, db13, dln[:H], dln[H:]
 
 
 class FromNaturalFn(torch.autograd.Function):
@@ -188,36 +230,70 @@ class FromNaturalFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------
-# featurizer embedding (ATen, edge form: O(L K), never L x L)
+# featurizer: RBF + positional embedding -> edge_embedding -> norm_edges -> W_e   (reference :334-358, :464)
 # ---------------------------------------------------------------------------
-def _edge_embedding(fm, atoms, g: Graph, residue_idx, chain_labels):
-    """reference :334-358: [positional(16) | 25 or 36 RBF blocks] -> edge_embedding -> norm_edges."""
-    na = 6 if fm.use_virtual_center else 5
-    pos = atoms.view(g.N, 6, 4)[:, :na, :3]
-    nb = pos[g.dest].view(g.N, g.K, 1, na, 3)
-    D = torch.sqrt(((pos.view(g.N, 1, na, 1, 3) - nb) ** 2).sum(-1) + 1e-6)          # [N,K,na(i),na(j)]
-    mu = torch.linspace(2.0, 22.0, fm.num_rbf, device=atoms.device)
-    sigma = (22.0 - 2.0) / fm.num_rbf
-    rbf = torch.exp(-(((D.unsqueeze(-1) - mu) / sigma) ** 2)).reshape(g.N, g.K, na * na * fm.num_rbf)
-    ri, cl = residue_idx.reshape(-1), chain_labels.reshape(-1)
-    m = fm.embeddings.max_relative_feature
-    off = ri[g.src] - ri[g.dest]
-    same = (cl[g.src] == cl[g.dest]).long()
-    d = torch.clip(off + m, 0, 2 * m) * same + (1 - same) * (2 * m + 1)
-    lin = fm.embeddings.linear
-    # one-hot -> linear exactly as the reference writes it (:170-176): its backward is a GEMM, where an index lookup's
-    # backward is a 491k-row scatter into 66 rows (measured 38 ms per step at 20 x 512)
-    E_pos = F.linear(F.one_hot(d, 2 * m + 2).to(torch.float32), lin.weight, lin.bias).view(g.N, g.K, -1)
-    E = F.linear(torch.cat([E_pos, rbf], -1), fm.edge_embedding.weight)
-    return F.layer_norm(E, (E.shape[-1],), fm.norm_edges.weight, fm.norm_edges.bias, 1e-5)
+class FeaturesFn(torch.autograd.Function):
+    """hE0 (fragment layout) from backbone atoms; parameters: embeddings.linear, edge_embedding, norm_edges, W_e."""
+
+    @staticmethod
+    def forward(ctx, g, atoms, residue_idx, chain_labels, n_atoms, Wpos, bpos, Wemb, lnw, lnb, We, be):
+        dev = atoms.device
+        st = stream_ptr()
+        table = torch.empty(66 * 16, device=dev, dtype=torch.float32)
+        Wl, bl = Wpos.detach().contiguous(), bpos.detach().contiguous()
+        call("mpnn_pos_table", ptr(Wl), ptr(bl), 66, 16, ptr(table), st)
+        mu = torch.linspace(2.0, 22.0, 16, device=dev, dtype=torch.float32)
+        Wc = Wemb.detach().contiguous()
+        nkk = (Wc.shape[1] + 31) // 32
+        Wemb_p = torch.empty(8 * nkk * 512, device=dev, dtype=torch.float32)
+        call("mpnn_pack_linear_split", ptr(Wc), H, Wc.shape[1], Wc.shape[1], 0, 16, ptr(Wemb_p), st)
+        We_p = _pack_split(We)
+        vec = [t.detach().contiguous() for t in (lnw, lnb, be)]
+        hE = torch.empty(g.frag_numel(), device=dev, dtype=torch.float32)
+        E0, E = torch.empty_like(hE), torch.empty_like(hE)
+        call("mpnn_edge_features_train", ptr(atoms), ptr(g.E_idx32), ptr(residue_idx), ptr(chain_labels), ptr(table),
+             ptr(mu), ptr(Wemb_p), ptr(vec[0]), ptr(vec[1]), ptr(We_p), ptr(vec[2]), g.B, g.L, g.K, n_atoms, ptr(E0),
+             ptr(E), ptr(hE), st)
+        ctx.g, ctx.n_atoms = g, n_atoms
+        ctx.save_for_backward(atoms, residue_idx, chain_labels, table, mu, E0, E, Wemb, lnw, We)
+        return hE
+
+    @staticmethod
+    def backward(ctx, dhE):
+        g, na = ctx.g, ctx.n_atoms
+        atoms, residue_idx, chain_labels, table, mu, E0, E, Wemb, lnw, We = ctx.saved_tensors
+        dev = dhE.device
+        st = stream_ptr()
+        dhE = dhE.contiguous()
+        dE0 = torch.empty_like(E0)
+        dln = torch.zeros(2 * H, device=dev, dtype=torch.float32)
+        amax = torch.zeros(2, device=dev, dtype=torch.float32)
+        wet = _pack_split(We.detach().t())
+        call("mpnn_edge_features_bwd", ptr(dhE), ptr(E0), ptr(lnw.detach().contiguous()), ptr(wet), g.B, g.L, g.K,
+             ptr(dE0), ptr(dln), ptr(amax), st)
+        dWe, dbe = _wgrad(dhE, False, amax[0:1], E, False, g, True)
+        nrbf = na * na * 16
+        nch = (na * na + 5 + 7) // 8
+        chunks = torch.empty(nch * g.frag_numel(), device=dev, dtype=torch.float32)
+        call("mpnn_feature_chunks", ptr(atoms), ptr(g.E_idx32), ptr(residue_idx), ptr(chain_labels), ptr(mu), g.B, g.L,
+             g.K, na, ptr(chunks), st)
+        n = g.frag_numel()
+        dF = torch.cat([_wgrad(dE0, False, amax[1:2], chunks[c * n:(c + 1) * n], False, g, False)[0]
+                        for c in range(nch)], dim=1)                       # [128, nch*128]: d / d(raw feature)
+        G = dF[:, nrbf:nrbf + 66]                                           # sum of dE0 rows per position bucket
+        W = Wemb.detach()
+        npos = W.shape[1] - nrbf
+        dT = G.t() @ W[:, :npos]                                            # gradient of the 66 x 16 embedding table
+        dWemb = torch.cat([G @ table.view(66, 16), dF[:, :nrbf]], dim=1)
+        return (None, None, None, None, None, dT.t().contiguous(), dT.sum(0), dWemb, dln[:H], dln[H:], dWe, dbe)
 
 
 def _node_tail(lyr, hV, gsum, cnt, mask_col, p_drop, training):
     """dh = (W3 gsum + cnt b3) / scale; norm1; FFN; norm2; mask   (reference :81-89, :127-138)."""
-    dh = (F.linear(gsum, lyr.W3.weight) + cnt.unsqueeze(-1) * lyr.W3.bias) / lyr.scale
+    dh = (linear(gsum, lyr.W3.weight) + cnt.unsqueeze(-1) * lyr.W3.bias) / lyr.scale
     hV = lyr.norm1(hV + F.dropout(dh, p_drop, training))
-    ff = F.linear(F.gelu(F.linear(hV, lyr.dense.W_in.weight, lyr.dense.W_in.bias)), lyr.dense.W_out.weight,
-                  lyr.dense.W_out.bias)
+    ff = linear(F.gelu(linear(hV, lyr.dense.W_in.weight, lyr.dense.W_in.bias)), lyr.dense.W_out.weight,
+                lyr.dense.W_out.bias)
     hV = lyr.norm2(hV + F.dropout(ff, p_drop, training))
     return mask_col * hV
 
@@ -244,8 +320,10 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
         g = Graph(E_idx64, E_idx32, mask.reshape(-1).contiguous(), edge_mask, K)
     if K > 48:
         raise NotImplementedError("mpnn_amd training kernels cover k_neighbors <= 48")
-    E = _edge_embedding(fm, atoms, g, residue_idx, chain_labels)
-    hE = FromNaturalFn.apply(g, F.linear(E, model.W_e.weight, model.W_e.bias))
+    hE = FeaturesFn.apply(g, atoms, residue_idx, chain_labels, 6 if fm.use_virtual_center else 5,
+                          fm.embeddings.linear.weight, fm.embeddings.linear.bias, fm.edge_embedding.weight,
+                          fm.norm_edges.weight, fm.norm_edges.bias, model.W_e.weight, model.W_e.bias)
+    slot = GradSlot()
     hV = torch.zeros(N, H, device=dev, dtype=torch.float32)
     if model.occupancy_mlp is not None and occ is not None:
         hV = hV + model.occupancy_mlp(occ.view(N, 1))
@@ -253,12 +331,13 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
 
     for lyr in model.encoder_layers:
         W1, W11 = lyr.W1.weight, lyr.W11.weight
-        P, Q = F.linear(hV, W1[:, :H], lyr.W1.bias), F.linear(hV, W1[:, 2 * H:])
-        gsum, cnt = MessageFn.apply(g, False, hE, P, Q, None, W1[:, H:2 * H], lyr.W2.weight, lyr.W2.bias)
+        P, Q = linear(hV, W1[:, :H], lyr.W1.bias), linear(hV, W1[:, 2 * H:])
+        gsum, cnt = MessageFn.apply(g, slot, False, hE, P, Q, None, W1[:, H:2 * H], lyr.W2.weight, lyr.W2.bias)
         hV = _node_tail(lyr, hV, gsum, cnt, mcol, p_drop, training)
-        P, Q = F.linear(hV, W11[:, :H], lyr.W11.bias), F.linear(hV, W11[:, 2 * H:])
-        hE = EdgeUpdateFn.apply(g, hE, P, Q, W11[:, H:2 * H], lyr.W12.weight, lyr.W12.bias, lyr.W13.weight,
+        P, Q = linear(hV, W11[:, :H], lyr.W11.bias), linear(hV, W11[:, 2 * H:])
+        hE = EdgeUpdateFn.apply(g, slot, hE, P, Q, W11[:, H:2 * H], lyr.W12.weight, lyr.W12.bias, lyr.W13.weight,
                                 lyr.W13.bias, lyr.norm3.weight, lyr.norm3.bias)
+        slot = GradSlot()
 
     if len(model.decoder_layers):
         with torch.no_grad():
@@ -274,12 +353,12 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
         hV_enc = hV
         for lyr in model.decoder_layers:
             W1 = lyr.W1.weight
-            Pa = F.linear(hV, W1[:, :H], lyr.W1.bias)
-            A = F.linear(hV, W1[:, 3 * H:]) + F.linear(hS, W1[:, 2 * H:3 * H])
-            Benc = F.linear(hV_enc, W1[:, 3 * H:])
-            gsum, cnt = MessageFn.apply(g, True, hE, Pa, A, Benc, W1[:, H:2 * H], lyr.W2.weight, lyr.W2.bias)
+            Pa = linear(hV, W1[:, :H], lyr.W1.bias)
+            A = linear(hV, W1[:, 3 * H:]) + linear(hS, W1[:, 2 * H:3 * H])
+            Benc = linear(hV_enc, W1[:, 3 * H:])
+            gsum, cnt = MessageFn.apply(g, slot, True, hE, Pa, A, Benc, W1[:, H:2 * H], lyr.W2.weight, lyr.W2.bias)
             hV = _node_tail(lyr, hV, gsum, cnt, mcol, p_drop, training)
-    logits = F.linear(hV, model.W_out.weight, model.W_out.bias)
+    logits = linear(hV, model.W_out.weight, model.W_out.bias)
     return F.log_softmax(logits, dim=-1).view(B, L, -1)
 
 
