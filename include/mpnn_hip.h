@@ -166,9 +166,11 @@ int mpnn_enc_edge_update_bwd(const float* dy_frag, const float* z_frag, const fl
  * gradients of one per-edge 128x128 layer).  A: fragment layout, or rows when a_rows != 0; B: fragment layout,
  * f = GELU when b_gelu != 0.  dW [128,128] row-major, accumulated with atomics (zero it first); dbias may be NULL.
  * A_absmax: device scalar >= max |A| (any positive value of that magnitude): gradients are tiny, so A is scaled by a
- * power of two derived from it before the f16 hi/lo split and the result scaled back. */
+ * power of two derived from it before the f16 hi/lo split and the result scaled back.
+ * workspace: device scratch for per-workgroup partial sums, 16512 floats per workgroup; 512 x 16512 floats lets the
+ * launch fill the chip (fewer -> fewer workgroups). */
 int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax, const float* B_frag, int b_gelu, int n_nodes,
-                    int K, float* dW, float* dbias, void* stream);
+                    int K, float* dW, float* dbias, float* workspace, int workspace_floats, void* stream);
 
 /* Gradient of the neighbour gather h[E_idx]: outA[j] = sum of rows[inv_row[m]] for m in [inv_ptr[j], inv_ptr[j+1]),
  * split between outA (sel[m] == 0) and outB (sel[m] != 0) when sel is given (decoder: which block the edge read). */
@@ -198,9 +200,10 @@ int mpnn_feature_chunks(const float* atoms, const int32_t* E_idx32, const int64_
 
 /* Weight / bias gradient of an nn.Linear over per-residue rows (autograd of the node-level linears, :78-93, :151-155):
  * dW[o][i] += sum_n dY[n][o] X[n][i]  (row strides ldy, ldx, ldw; fp32 products), dbias[o] += sum_n dY[n][o].
- * Accumulates with atomics: zero dW / dbias first.  dbias may be NULL. */
+ * Accumulates: zero dW / dbias first.  dbias may be NULL.  workspace: device scratch, 16512 floats per 128x128 output
+ * block and row chunk (256 chunks per block fill the chip). */
 int mpnn_node_wgrad(const float* dY, int ldy, int out_f, const float* X, int ldx, int in_f, int n_rows, float* dW,
-                    int ldw, float* dbias, void* stream);
+                    int ldw, float* dbias, float* workspace, int workspace_floats, void* stream);
 
 #ifdef __cplusplus
 }

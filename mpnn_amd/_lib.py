@@ -43,12 +43,12 @@ SIGNATURES = {
     "mpnn_enc_edge_update_train": [_P] * 11 + [_I] * 3 + [_P] * 5,
     "mpnn_message_bwd": [_I] + [_P] * 8 + [_I] * 3 + [_P] * 4 + [_I, _P, _P],
     "mpnn_enc_edge_update_bwd": [_P] * 8 + [_I] * 3 + [_P] * 8,
-    "mpnn_edge_wgrad": [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P],
+    "mpnn_edge_wgrad": [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P],
     "mpnn_gather_rows": [_P] * 4 + [_I] + [_P] * 3,
     "mpnn_edge_features_train": [_P] * 11 + [_I, _I, _I, _I, _P, _P, _P, _P],
     "mpnn_edge_features_bwd": [_P] * 4 + [_I] * 3 + [_P] * 4,
     "mpnn_feature_chunks": [_P] * 5 + [_I] * 4 + [_P, _P],
-    "mpnn_node_wgrad": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P],
+    "mpnn_node_wgrad": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P],
 }
 
 _lib = None

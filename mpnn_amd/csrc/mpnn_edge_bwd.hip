@@ -392,12 +392,13 @@ k_features_bwd(const f32x4* __restrict__ dy, const f32x4* __restrict__ E0, const
 // 2 x 8 output tiles with v_mfma_f32_16x16x16_f16 (3 products per tile: lo*hi + hi*lo + hi*hi).
 // ---------------------------------------------------------------------------
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+constexpr int WG_PART = MPNN_H * MPNN_H + MPNN_H;  // floats of one workgroup partial (dW | dbias)
 constexpr int WG_LDK = 52;  // padded edge stride (halves): 104-byte rows spread the 8-byte operand reads over banks
 
 template <bool A_NAT, bool B_GELU>
 __global__ void __launch_bounds__(256)
 k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigned* __restrict__ amax, int N, int KT,
-        float* __restrict__ dW, float* __restrict__ db) {
+        float* __restrict__ part) {
   __shared__ _Float16 sA[2][MPNN_H][WG_LDK];
   __shared__ _Float16 sB[2][MPNN_H][WG_LDK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -411,31 +412,51 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
   f32x4 bacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   const f32x4* Af = reinterpret_cast<const f32x4*>(A);
   const float sc = pow2_scale_from_bits(*amax), un = pow2_inverse(sc);  // see grad_to_bfrag
-  for (int node = blockIdx.x; node < N; node += gridDim.x) {
-    __syncthreads();  // previous residue's operand reads are done
+  // this thread's share of a residue: feature tiles t = 2 wave + {0, 1}, every column tile (<= 3)
+  f32x4 va[2][3], vb[2][3];
+  auto fetch = [&](int node) {
+#pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       const int t = 2 * wave + tt;
-      for (int c = 0; c < KT; ++c) {
-        f32x4 va, vb;
-        if (A_NAT)
-          va = *reinterpret_cast<const f32x4*>(A + ((size_t)node * Kp + 16 * c + col) * MPNN_H + 16 * t + 4 * g);
-        else
-          va = Af[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane];
-        vb = Bf[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane];
-        if (B_GELU) vb = gelu4(vb);
-        bacc[tt] += va;
-        va *= sc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const _Float16 ah = (_Float16)va[r], bh = (_Float16)vb[r];
-          sA[0][16 * t + 4 * g + r][16 * c + col] = ah;
-          sA[1][16 * t + 4 * g + r][16 * c + col] = (_Float16)(va[r] - (float)ah);
-          sB[0][16 * t + 4 * g + r][16 * c + col] = bh;
-          sB[1][16 * t + 4 * g + r][16 * c + col] = (_Float16)(vb[r] - (float)bh);
+      for (int c = 0; c < 3; ++c) {
+        if (c < KT) {
+          if (A_NAT)
+            va[tt][c] = *reinterpret_cast<const f32x4*>(A + ((size_t)node * Kp + 16 * c + col) * MPNN_H + 16 * t + 4 * g);
+          else
+            va[tt][c] = Af[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane];
+          vb[tt][c] = Bf[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane];
+        }
+      }
+    }
+  };
+  int node = blockIdx.x;
+  if (node < N) fetch(node);
+  for (; node < N; node += gridDim.x) {
+    __syncthreads();  // previous residue's operand reads are done
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = 2 * wave + tt;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (c < KT) {
+          f32x4 a = va[tt][c], b = vb[tt][c];
+          if (B_GELU) b = gelu4(b);
+          bacc[tt] += a;
+          a *= sc;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const _Float16 ah = (_Float16)a[r], bh = (_Float16)b[r];
+            sA[0][16 * t + 4 * g + r][16 * c + col] = ah;
+            sA[1][16 * t + 4 * g + r][16 * c + col] = (_Float16)(a[r] - (float)ah);
+            sB[0][16 * t + 4 * g + r][16 * c + col] = bh;
+            sB[1][16 * t + 4 * g + r][16 * c + col] = (_Float16)(b[r] - (float)bh);
+          }
         }
       }
     }
     __syncthreads();
+    if (node + (int)gridDim.x < N) fetch(node + gridDim.x);  // next residue's loads fly under the MFMAs
     for (int c = 0; c < KT; ++c) {
       h4 ah[2], al[2];
 #pragma unroll
@@ -456,28 +477,41 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
       }
     }
   }
+  // this workgroup's partial [128 x 128 | 128 bias sums] -> workspace (plain stores; k_wgrad_reduce adds them up:
+  // 2^23 same-address-set atomics per launch from 512 workgroups cost more than the whole contraction)
+  float* P = part + (size_t)blockIdx.x * WG_PART;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < MPNN_NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        unsafeAtomicAdd(dW + (size_t)(16 * (2 * wave + i) + 4 * g + r) * MPNN_H + 16 * j + col, acc[i][j][r] * un);
-  if (db) {
+      for (int r = 0; r < 4; ++r) P[(16 * (2 * wave + i) + 4 * g + r) * MPNN_H + 16 * j + col] = acc[i][j][r] * un;
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+  for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = column_sum(bacc[tt][r]);
-        if (col == 0) unsafeAtomicAdd(db + 16 * (2 * wave + tt) + 4 * g + r, v);
-      }
-  }
+    for (int r = 0; r < 4; ++r) {
+      const float v = column_sum(bacc[tt][r]);
+      if (col == 0) P[MPNN_H * MPNN_H + 16 * (2 * wave + tt) + 4 * g + r] = v;
+    }
+}
+
+// dW[i] += sum_w part[w][i]  (slice blockIdx.y of the partials; slices meet with one atomic per element)
+__global__ void __launch_bounds__(256)
+k_wgrad_reduce(const float* __restrict__ part, int nparts, float* __restrict__ dW, float* __restrict__ db) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= WG_PART) return;
+  float s = 0.f;
+  for (int w = blockIdx.y; w < nparts; w += gridDim.y) s += part[(size_t)w * WG_PART + i];
+  if (i < MPNN_H * MPNN_H)
+    unsafeAtomicAdd(dW + i, s);
+  else if (db)
+    unsafeAtomicAdd(db + (i - MPNN_H * MPNN_H), s);
 }
 
 // ---------------------------------------------------------------------------
 // out[j] = sum of the rows listed for node j (inverse neighbour list: rows that gathered node j in forward).
 // sel (optional, per list entry): 0 -> outA, 1 -> outB  (decoder: row came from the A or the encoder block)
-// One wave per destination node, 512-byte coalesced row reads, four rows in flight.
+// One wave per destination node, 512-byte coalesced row reads, eight rows in flight.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_gather_rows(const float* __restrict__ rows, const int* __restrict__ inv_ptr, const int* __restrict__ inv_row,
@@ -488,16 +522,16 @@ k_gather_rows(const float* __restrict__ rows, const int* __restrict__ inv_ptr, c
   const int m0 = inv_ptr[j], m1 = inv_ptr[j + 1];
   float2 sa = make_float2(0.f, 0.f), sb = sa;
   int m = m0;
-  for (; m + 4 <= m1; m += 4) {
-    float2 v[4];
-    int fl[4];
+  for (; m + 8 <= m1; m += 8) {
+    float2 v[8];
+    int fl[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       v[u] = *reinterpret_cast<const float2*>(rows + (size_t)inv_row[m + u] * MPNN_H + 2 * lane);
       fl[u] = sel ? sel[m + u] : 0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       if (fl[u]) { sb.x += v[u].x; sb.y += v[u].y; } else { sa.x += v[u].x; sa.y += v[u].y; }
     }
   }
@@ -561,8 +595,9 @@ extern "C" int mpnn_enc_edge_update_bwd(const float* dy_frag, const float* z_fra
 }
 
 extern "C" int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax, const float* B_frag, int b_gelu,
-                               int n_nodes, int K, float* dW, float* dbias, void* stream) {
-  MPNN_CHECK_ARG(A && A_absmax && B_frag && dW, "mpnn_edge_wgrad: null pointer");
+                               int n_nodes, int K, float* dW, float* dbias, float* workspace, int workspace_floats,
+                               void* stream) {
+  MPNN_CHECK_ARG(A && A_absmax && B_frag && dW && workspace, "mpnn_edge_wgrad: null pointer");
   MPNN_CHECK_ARG(n_nodes > 0 && K >= 1 && K <= 48, "mpnn_edge_wgrad: bad sizes (K <= 48)");
   const int KT = (K + 15) / 16;
   int dev = 0, cus = 256;
@@ -570,17 +605,22 @@ extern "C" int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
-  dim3 grid(n_nodes < 2 * cus ? n_nodes : 2 * cus), block(256);
+  int nwg = n_nodes < 2 * cus ? n_nodes : 2 * cus;
+  if (nwg > workspace_floats / WG_PART) nwg = workspace_floats / WG_PART;
+  MPNN_CHECK_ARG(nwg >= 1, "mpnn_edge_wgrad: workspace holds no partial (needs >= 16512 floats, ideally 512 x 16512)");
+  dim3 grid(nwg), block(256);
   hipStream_t st = (hipStream_t)stream;
   const f32x4* Bf = (const f32x4*)B_frag;
   const unsigned* am = (const unsigned*)A_absmax;
   if (a_rows) {
-    if (b_gelu) hipLaunchKernelGGL((k_wgrad<true, true>), grid, block, 0, st, A, Bf, am, n_nodes, KT, dW, dbias);
-    else hipLaunchKernelGGL((k_wgrad<true, false>), grid, block, 0, st, A, Bf, am, n_nodes, KT, dW, dbias);
+    if (b_gelu) hipLaunchKernelGGL((k_wgrad<true, true>), grid, block, 0, st, A, Bf, am, n_nodes, KT, workspace);
+    else hipLaunchKernelGGL((k_wgrad<true, false>), grid, block, 0, st, A, Bf, am, n_nodes, KT, workspace);
   } else {
-    if (b_gelu) hipLaunchKernelGGL((k_wgrad<false, true>), grid, block, 0, st, A, Bf, am, n_nodes, KT, dW, dbias);
-    else hipLaunchKernelGGL((k_wgrad<false, false>), grid, block, 0, st, A, Bf, am, n_nodes, KT, dW, dbias);
+    if (b_gelu) hipLaunchKernelGGL((k_wgrad<false, true>), grid, block, 0, st, A, Bf, am, n_nodes, KT, workspace);
+    else hipLaunchKernelGGL((k_wgrad<false, false>), grid, block, 0, st, A, Bf, am, n_nodes, KT, workspace);
   }
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((WG_PART + 255) / 256, nwg < 16 ? nwg : 16), dim3(256), 0, st, workspace, nwg, dW,
+                     dbias);
   MPNN_LAUNCH_CHECK();
 }
 

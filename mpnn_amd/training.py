@@ -71,10 +71,11 @@ def _pack_split(W):
 
 
 def _wgrad(A, a_rows, amax, Bfrag, b_gelu, g, want_bias):
-    dW = torch.zeros(H, H, device=A.device, dtype=torch.float32)
-    db = torch.zeros(H, device=A.device, dtype=torch.float32) if want_bias else None
+    dW = _zeros(A.device, H, H)
+    db = _zeros(A.device, H) if want_bias else None
+    ws = _workspace(A.device)
     call("mpnn_edge_wgrad", ptr(A), int(a_rows), ptr(amax), ptr(Bfrag), int(b_gelu), g.N, g.K, ptr(dW), ptr(db),
-         stream_ptr())
+         ptr(ws), ws.numel(), stream_ptr())
     return dW, db
 
 
@@ -84,6 +85,50 @@ def _gather(rows, g, sel):
     call("mpnn_gather_rows", ptr(rows), ptr(g.inv_ptr), ptr(g.inv_row), ptr(sel), g.N, ptr(outA), ptr(outB),
          stream_ptr())
     return outA, outB
+
+
+_WS = {}
+
+
+class _ZeroArena:
+    """One zero-filled block per backward pass, handed out in slices: the ~190 small gradient accumulators of a step
+    (dW, dbias, LayerNorm sums, |max| scalars) would otherwise cost one fill launch each."""
+
+    def __init__(self):
+        self.buf = None
+        self.used = 0
+
+    def reset(self, dev, n_floats=4 << 20):
+        self.buf = torch.zeros(n_floats, device=dev, dtype=torch.float32)
+        self.used = 0
+
+    def take(self, *shape):
+        n = 1
+        for d in shape:
+            n *= d
+        n_al = (n + 63) & ~63  # 256-byte aligned slices
+        if self.buf is None or self.used + n_al > self.buf.numel():
+            return torch.zeros(shape, device=self.buf.device if self.buf is not None else None, dtype=torch.float32)
+        out = self.buf[self.used:self.used + n].view(shape)
+        self.used += n_al
+        return out
+
+
+_ZEROS = _ZeroArena()
+
+
+def _zeros(dev, *shape):
+    if _ZEROS.buf is None or _ZEROS.buf.device != dev:
+        return torch.zeros(shape, device=dev, dtype=torch.float32)
+    return _ZEROS.take(*shape)
+
+
+def _workspace(dev):
+    """Per-device scratch for the weight-gradient kernels' partial sums (calls on one stream reuse it in order)."""
+    ws = _WS.get(dev)
+    if ws is None:
+        ws = _WS[dev] = torch.empty(512 * 16512, device=dev, dtype=torch.float32)
+    return ws
 
 
 class LinearFn(torch.autograd.Function):
@@ -102,10 +147,11 @@ class LinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         x = x.contiguous()
         dx = dy @ W if ctx.needs_input_grad[0] else None
-        dW = torch.zeros(W.shape, device=dy.device, dtype=torch.float32)
-        db = torch.zeros(W.shape[0], device=dy.device, dtype=torch.float32) if ctx.has_bias else None
+        dW = _zeros(dy.device, *W.shape)
+        db = _zeros(dy.device, W.shape[0]) if ctx.has_bias else None
+        ws = _workspace(dy.device)
         call("mpnn_node_wgrad", ptr(dy), dy.shape[1], dy.shape[1], ptr(x), x.shape[1], x.shape[1], dy.shape[0], ptr(dW),
-             dW.shape[1], ptr(db), stream_ptr())
+             dW.shape[1], ptr(db), ptr(ws), ws.numel(), stream_ptr())
         return dx, dW, db
 
 
@@ -163,7 +209,7 @@ class MessageFn(torch.autograd.Function):
             slot.buf = torch.empty_like(a1)
         dE = slot.buf
         w2t, w1t = _pack_split(W2.detach().t()), _pack_split(W1b.detach().t())
-        amax = torch.zeros(2, device=dev, dtype=torch.float32)
+        amax = _zeros(dev, 2)
         call("mpnn_message_bwd", int(dec), ptr(dgsum), ptr(a1), ptr(a2), ptr(g.E_idx32), ptr(g.mask), ptr(g.edge_mask),
              ptr(w2t), ptr(w1t), g.B, g.L, g.K, ptr(da2), ptr(rows),
              ptr(dP), ptr(dE), 0 if first else 1, ptr(amax), stream_ptr())
@@ -202,8 +248,8 @@ class EdgeUpdateFn(torch.autograd.Function):
         ctx.slot.buf = dE
         rows = torch.empty(g.N * g.Kp, H, device=dev, dtype=torch.float32)
         dP = torch.empty(g.N, H, device=dev, dtype=torch.float32)
-        dln = torch.zeros(2 * H, device=dev, dtype=torch.float32)
-        amax = torch.zeros(3, device=dev, dtype=torch.float32)
+        dln = _zeros(dev, 2 * H)
+        amax = _zeros(dev, 3)
         w3t, w2t, w1t = _pack_split(W13.detach().t()), _pack_split(W12.detach().t()), _pack_split(W11b.detach().t())
         call("mpnn_enc_edge_update_bwd", ptr(dy), ptr(z), ptr(a2), ptr(a1), ptr(lnw.detach().contiguous()),
              ptr(w3t), ptr(w2t), ptr(w1t),
@@ -266,8 +312,8 @@ class FeaturesFn(torch.autograd.Function):
         st = stream_ptr()
         dhE = dhE.contiguous()
         dE0 = torch.empty_like(E0)
-        dln = torch.zeros(2 * H, device=dev, dtype=torch.float32)
-        amax = torch.zeros(2, device=dev, dtype=torch.float32)
+        dln = _zeros(dev, 2 * H)
+        amax = _zeros(dev, 2)
         wet = _pack_split(We.detach().t())
         call("mpnn_edge_features_bwd", ptr(dhE), ptr(E0), ptr(lnw.detach().contiguous()), ptr(wet), g.B, g.L, g.K,
              ptr(dE0), ptr(dln), ptr(amax), st)
@@ -314,6 +360,7 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
     if p_drop > 0 and training and len(model.encoder_layers):
         raise NotImplementedError("mpnn_amd training: edge-level dropout (EncLayer.dropout3) is not built yet; "
                                   "construct the model with dropout=0.0")
+    _ZEROS.reset(dev)  # gradient accumulators of this step's backward pass
     with torch.no_grad():
         atoms, _, E_idx64, E_idx32, _, edge_mask, K = engine._geometry(fm, X, mask, fix_backbone_noise, training)
         occ = engine._occupancy(fm, atoms, mask, B, L)

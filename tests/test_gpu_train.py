@@ -126,7 +126,9 @@ def test_wgrad_and_gather_kernels():
             db = torch.zeros(128, device=d)
             src = (A_rows if a_rows else A_frag) * scale
             amax = src.abs().max().reshape(1)
-            call("mpnn_edge_wgrad", ptr(src), a_rows, ptr(amax), ptr(B_frag), gelu, N, K, ptr(dW), ptr(db), stream_ptr())
+            ws = torch.empty(37 * 16512, device=d)  # room for 37 workgroup partials only
+            call("mpnn_edge_wgrad", ptr(src), a_rows, ptr(amax), ptr(B_frag), gelu, N, K, ptr(dW), ptr(db), ptr(ws),
+                 ws.numel(), stream_ptr())
             dW, db = dW / scale, db / scale
             Bx = torch.nn.functional.gelu(B_nat) if gelu else B_nat
             want = torch.einsum("nko,nki->oi", A_nat.double(), Bx.double())
