@@ -205,6 +205,41 @@ int mpnn_feature_chunks(const float* atoms, const int32_t* E_idx32, const int64_
 int mpnn_node_wgrad(const float* dY, int ldy, int out_f, const float* X, int ldx, int in_f, int n_rows, float* dW,
                     int ldw, float* dbias, float* workspace, int workspace_floats, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Autoregressive sampling (BASELINE configs[4]).  The reference has no sampler; the contract is
+ * that a teacher-forced forward (:427-529) on the sampled sequence with the same decoding order returns, at every
+ * residue, the log-probs the sampler drew from.  Samples of one structure share the encoder output: encoder-side
+ * arrays hold enc_nodes = P * L residues, sample-side arrays n_samples * enc_nodes, residue id = s * enc_nodes + n.
+ * Residues are processed in dependency levels (a residue's level = 1 + max level of its already-decoded
+ * neighbours), each level being one launch per kernel over node_list.
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* mpnn_dec_message for the residues in node_list: hE / E_idx32 / edge_mask / PVenc are indexed with
+ * (residue % enc_nodes); P, RowA, rank, mask, gsum with the residue id. */
+int mpnn_dec_message_subset(const float* hE_frag, const float* P, int ldp, int offP, const float* RowA, int lda,
+                            int offA, const float* PVenc, int ldenc, int offEnc, const int32_t* rank,
+                            const int32_t* E_idx32, const float* mask, const float* edge_mask, const float* W1b_packed,
+                            const float* W2_packed, const float* b2, const int32_t* node_list, int n_list,
+                            int enc_nodes, int L, int K, float* gsum, void* stream);
+
+/* mpnn_node_update (do_update = 1, cnt = cnt_const, no table add) for the residues in node_list. */
+int mpnn_node_update_subset(const float* hV_in, const float* gsum, float cnt_const, const float* mask,
+                            const float* W3_packed, const float* b3, const float* ln1_w, const float* ln1_b,
+                            const float* Win_packed, const float* b_in, const float* Wout_packed, const float* b_out,
+                            const float* ln2_w, const float* ln2_b, float scale, const float* Wproj_packed,
+                            const float* bproj, int nproj, const int32_t* node_list, int n_list, float* hV_out,
+                            float* PQ, void* stream);
+
+/* Output head + draw for the residues in node_list: log_probs = log_softmax(W_out h + b) (:527-528);
+ * S ~ softmax((logits + logit_bias) / temperature) where designable[n] != 0 (uniform variate = splitmix64(seed,
+ * residue id)), else S = S_in[n]; then A_rows[l][n * A_ld[l] + A_off[l] ..+128] += TS[S][128 l ..] for every decoder
+ * layer l < n_layers <= 4 (the sequence term W1c W_s[S], :478-479).  A_rows / A_ld / A_off are HOST arrays. */
+int mpnn_sample_subset(const float* hV, const float* Wout_packed, const float* bias, const float* logit_bias,
+                       int n_letters, const int32_t* node_list, int n_list, float temperature, uint64_t seed,
+                       const float* designable, const int64_t* S_in, int64_t* S_out, float* log_probs,
+                       const float* TS, int ld_ts, int n_layers, float* const* A_rows, const int* A_ld,
+                       const int* A_off, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,14 +36,15 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
               float inv_scale, int do_update, const h8* __restrict__ Wproj, const float* __restrict__ bproj,
               int nproj, const float* __restrict__ add_table, int ld_table, int off_table,
               const long long* __restrict__ add_idx, int add_block, int N, float* __restrict__ hV_out,
-              float* __restrict__ PQ) {
+              float* __restrict__ PQ, const int* __restrict__ node_list) {
   __shared__ h8 lds[2 * WSPLIT];
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int g = lane >> 4, col = lane & 15;
   const int node = tile * 16 + col;
   const bool live = node < N;       // no early exit: every wave takes part in the staging barriers
-  const int nd = live ? node : N - 1;
+  const int nd0 = live ? node : N - 1;
+  const int nd = node_list ? node_list[nd0] : nd0;  // sampling: the launch covers a listed subset of residues
 
   const int nmat = (do_update ? 9 : 0) + nproj;
   auto matrix = [&](int k) -> const h8* {
@@ -113,7 +114,7 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
       h[t][0] = o[t][0] * mk;
-      if (live) *reinterpret_cast<f32x4*>(hV_out + (size_t)node * MPNN_H + 16 * t + 4 * g) = h[t][0];
+      if (live) *reinterpret_cast<f32x4*>(hV_out + (size_t)nd * MPNN_H + 16 * t + 4 * g) = h[t][0];
     }
   }
   BFrag pb[NKK][1];
@@ -134,7 +135,7 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
     if (live) {
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t)
-        *reinterpret_cast<f32x4*>(PQ + (size_t)node * ld + p * MPNN_H + 16 * t + 4 * g) = y[t][0];
+        *reinterpret_cast<f32x4*>(PQ + (size_t)nd * ld + p * MPNN_H + 16 * t + 4 * g) = y[t][0];
     }
   }
 }
@@ -241,7 +242,174 @@ extern "C" int mpnn_node_update(const float* hV_in, const float* gsum, const flo
                      cnt_const, mask, (const h8*)W3_packed, b3, ln1_w, ln1_b, (const h8*)Win_packed, b_in,
                      (const h8*)Wout_packed, b_out, ln2_w, ln2_b, 1.0f / scale, do_update,
                      (const h8*)Wproj_packed, bproj, nproj, add_table, ld_table, off_table,
-                     (const long long*)add_idx, add_block, n_nodes, hV_out, PQ);
+                     (const long long*)add_idx, add_block, n_nodes, hV_out, PQ, (const int*)nullptr);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_node_update_subset(const float* hV_in, const float* gsum, float cnt_const, const float* mask,
+                                       const float* W3_packed, const float* b3, const float* ln1_w,
+                                       const float* ln1_b, const float* Win_packed, const float* b_in,
+                                       const float* Wout_packed, const float* b_out, const float* ln2_w,
+                                       const float* ln2_b, float scale, const float* Wproj_packed, const float* bproj,
+                                       int nproj, const int32_t* node_list, int n_list, float* hV_out, float* PQ,
+                                       void* stream) {
+  MPNN_CHECK_ARG(hV_in && gsum && mask && W3_packed && b3 && ln1_w && ln1_b && Win_packed && b_in && Wout_packed &&
+                     b_out && ln2_w && ln2_b && hV_out && node_list && n_list > 0 && nproj >= 0,
+                 "mpnn_node_update_subset: bad arguments");
+  MPNN_CHECK_ARG(nproj == 0 || (Wproj_packed && bproj && PQ), "mpnn_node_update_subset: projections need Wproj, bproj, PQ");
+  hipLaunchKernelGGL(k_node_update, dim3(ceil_div(n_list, 64)), dim3(256), 0, (hipStream_t)stream, hV_in, gsum,
+                     (const float*)nullptr, cnt_const, mask, (const h8*)W3_packed, b3, ln1_w, ln1_b,
+                     (const h8*)Win_packed, b_in, (const h8*)Wout_packed, b_out, ln2_w, ln2_b, 1.0f / scale, 1,
+                     (const h8*)Wproj_packed, bproj, nproj, (const float*)nullptr, 0, 0, (const long long*)nullptr, 0,
+                     n_list, hV_out, PQ, node_list);
+  MPNN_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// Sampling head for a listed subset of residues (one wave = 16 residues):
+//   logits = W_out h + b;  log_probs = log_softmax(logits)  (the model's distribution, what a teacher-forced
+//   forward returns at this position);  S ~ softmax((logits + bias) / temperature)  by inverse CDF with a
+//   counter-based uniform u(seed, residue);  fixed residues (designable[n] == 0) keep S_in[n].
+//   Then the residue's sequence term is folded into the decoder's gathered rows: A_l[n] += TS[S][128 l ..] for
+//   every decoder layer l (reference h_S = W_s(S) enters W1 through h_ES, :478-479, :513).
+// ---------------------------------------------------------------------------
+struct SampleRows {
+  float* A[4];
+  int ld[4], off[4];
+  int n_layers;
+};
+
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long ctr) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1);  // splitmix64
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);  // 24 bits -> [0, 1)
+}
+
+__global__ void __launch_bounds__(256)
+k_sample(const float* __restrict__ hV, const f32x4* __restrict__ Wp, const float* __restrict__ bias,
+         const float* __restrict__ logit_bias, int n_letters, const int* __restrict__ node_list, int N,
+         float inv_temperature, unsigned long long seed, const float* __restrict__ designable,
+         const long long* __restrict__ S_in, long long* __restrict__ S_out, float* __restrict__ log_probs,
+         const float* __restrict__ TS, int ld_ts, SampleRows rows) {
+  __shared__ float pr[4][16][33];
+  __shared__ int pick[4][16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tile = blockIdx.x * 4 + wv;
+  if (tile * 16 >= N) return;
+  const int g = lane >> 4, col = lane & 15;
+  const int idx = tile * 16 + col;
+  const bool live = idx < N;
+  const int nd = node_list[live ? idx : N - 1];
+  f32x4 h[MPNN_NT][1], y[2][1];
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) h[t][0] = *reinterpret_cast<const f32x4*>(hV + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int letter = 16 * t + 4 * g + r;
+      y[t][0][r] = letter < n_letters ? bias[letter] : 0.f;
+    }
+  tile_gemm<1, MPNN_NT, 0, 2>(Wp, lane, h, y);
+  // model log-probs
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (16 * t + 4 * g + r < n_letters) mx = fmaxf(mx, y[t][0][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float se = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (16 * t + 4 * g + r < n_letters) se += expf(y[t][0][r] - mx);
+  se = quarter_sum(se);
+  const float lse = mx + logf(se);
+  // tempered, biased weights for the draw
+  float z[2][4], zm = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int letter = 16 * t + 4 * g + r;
+      if (letter < n_letters) {
+        if (live) log_probs[(size_t)nd * n_letters + letter] = y[t][0][r] - lse;
+        z[t][r] = (y[t][0][r] + (logit_bias ? logit_bias[letter] : 0.f)) * inv_temperature;
+        zm = fmaxf(zm, z[t][r]);
+      }
+    }
+  zm = fmaxf(zm, __shfl_xor(zm, 16));
+  zm = fmaxf(zm, __shfl_xor(zm, 32));
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int letter = 16 * t + 4 * g + r;
+      if (letter < n_letters) pr[wv][col][letter] = expf(z[t][r] - zm);
+    }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  if (g == 0) {
+    int s = 0;
+    if (designable[nd] != 0.f) {
+      float tot = 0.f;
+      for (int a = 0; a < n_letters; ++a) tot += pr[wv][col][a];
+      const float u = uniform01(seed, (unsigned long long)nd) * tot;
+      float acc = 0.f;
+      s = n_letters - 1;
+      for (int a = 0; a < n_letters; ++a) {
+        acc += pr[wv][col][a];
+        if (u < acc) { s = a; break; }
+      }
+    } else {
+      s = (int)S_in[nd];
+    }
+    pick[wv][col] = s;
+    if (live) S_out[nd] = s;
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  // fold the sequence term of the chosen letter into every decoder layer's A rows (2 floats per lane per row)
+  const int nlive = min(16, N - tile * 16);
+  for (int c = 0; c < nlive; ++c) {
+    const int n = node_list[tile * 16 + c], s = pick[wv][c];
+    for (int l = 0; l < rows.n_layers; ++l) {
+      float2* dst = reinterpret_cast<float2*>(rows.A[l] + (size_t)n * rows.ld[l] + rows.off[l]) + lane;
+      const float2 add = *(reinterpret_cast<const float2*>(TS + (size_t)s * ld_ts + l * MPNN_H) + lane);
+      float2 v = *dst;
+      v.x += add.x;
+      v.y += add.y;
+      *dst = v;
+    }
+  }
+}
+
+extern "C" int mpnn_sample_subset(const float* hV, const float* Wout_packed, const float* bias, const float* logit_bias,
+                                  int n_letters, const int32_t* node_list, int n_list, float temperature,
+                                  uint64_t seed, const float* designable, const int64_t* S_in, int64_t* S_out,
+                                  float* log_probs, const float* TS, int ld_ts, int n_layers, float* const* A_rows,
+                                  const int* A_ld, const int* A_off, void* stream) {
+  MPNN_CHECK_ARG(hV && Wout_packed && bias && node_list && designable && S_in && S_out && log_probs && TS && A_rows &&
+                     A_ld && A_off,
+                 "mpnn_sample_subset: null pointer");
+  MPNN_CHECK_ARG(n_list > 0 && n_letters >= 1 && n_letters <= 32 && temperature > 0.f && n_layers >= 0 && n_layers <= 4,
+                 "mpnn_sample_subset: bad arguments (n_letters <= 32, temperature > 0, at most 4 decoder layers)");
+  SampleRows rows;
+  rows.n_layers = n_layers;
+  for (int l = 0; l < 4; ++l) {
+    rows.A[l] = l < n_layers ? A_rows[l] : nullptr;
+    rows.ld[l] = l < n_layers ? A_ld[l] : 0;
+    rows.off[l] = l < n_layers ? A_off[l] : 0;
+  }
+  hipLaunchKernelGGL(k_sample, dim3(ceil_div(n_list, 64)), dim3(256), 0, (hipStream_t)stream, hV,
+                     (const f32x4*)Wout_packed, bias, logit_bias, n_letters, node_list, n_list, 1.0f / temperature,
+                     (unsigned long long)seed, designable, (const long long*)S_in, (long long*)S_out, log_probs, TS,
+                     ld_ts, rows);
   MPNN_LAUNCH_CHECK();
 }
 

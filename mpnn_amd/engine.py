@@ -295,11 +295,9 @@ def _node_update(hV_in, n_nodes, lw, gsum, cnt, cnt_const, mask, group, hV_out, 
 # ---------------------------------------------------------------------------
 def forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order=None, fix_backbone_noise=None,
             return_intermediates: bool = False):
-    """ProteinMPNN.forward (reference :427-529) on the HIP kernels.  Inference only for now:
-    the backward kernels are not built yet, so a grad-requiring call fails loudly."""
+    """ProteinMPNN.forward (reference :427-529) on the HIP kernels, inference form (no autograd graph; the
+    differentiable form is training.forward_train, which ProteinMPNN.forward picks in training mode)."""
     _require_device(X, "X")
-    if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()) and model.training:
-        raise NotImplementedError("mpnn_amd: backward kernels are not built yet; call under torch.no_grad() / eval()")
     dev = X.device
     mask = _f32(mask)
     B, L = mask.shape
@@ -403,6 +401,144 @@ def forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_ord
         inter["log_probs"] = log_probs
         return inter
     return log_probs
+
+
+# ---------------------------------------------------------------------------
+# autoregressive sampling (BASELINE configs[4]; no reference function, contract in include/mpnn_hip.h)
+# ---------------------------------------------------------------------------
+def _encode(model, X, mask, residue_idx, chain_labels, backbone_noise):
+    """Featurizer + encoder stack (reference :441-470) -> dict(hE, hV, PQ, K, E_idx64, E_idx32, edge_mask).
+    PQ's trailing blocks are Pa_0 | A_0 (WITHOUT the sequence term) | PVenc_0 | PVenc_1 | ..."""
+    dev = X.device
+    B, L = mask.shape
+    N = B * L
+    pw = packed(model)
+    st = stream_ptr()
+    fm = model.features
+    atoms, _, E_idx64, E_idx32, _, edge_mask, K = _geometry(fm, X, mask, backbone_noise, model.training)
+    occ = _occupancy(fm, atoms, mask, B, L)
+    hE, _ = _edge_features(pw, atoms, E_idx32, residue_idx, chain_labels, B, L, K, False)
+    hV = torch.zeros(N, H, device=dev, dtype=torch.float32)
+    if pw.occ is not None and occ is not None:
+        o = pw.occ
+        call("mpnn_occupancy_mlp", ptr(occ), ptr(o["w0"]), ptr(o["b0"]), ptr(o["W2"]), ptr(o["b2"]), ptr(o["lnw"]),
+             ptr(o["lnb"]), N, ptr(hV), st)
+    gsum = torch.empty(N, H, device=dev, dtype=torch.float32)
+    cnt = torch.empty(N, device=dev, dtype=torch.float32)
+
+    def new_pq(group):
+        return torch.empty(N, max(group[2], 1) * H, device=dev, dtype=torch.float32) if group[2] else None
+
+    PQ = new_pq(pw.g_init)
+    if pw.g_init[2]:
+        _node_update(hV, N, None, None, None, 0.0, None, pw.g_init, None, PQ)
+    for l, lw in enumerate(pw.enc):
+        offP, offQ = (0, H) if l == 0 else (2 * H, 3 * H)
+        call("mpnn_enc_message", ptr(hE), ptr(PQ), PQ.shape[1], offP, offQ, ptr(E_idx32), ptr(mask), ptr(edge_mask),
+             ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"]), B, L, K, ptr(gsum), ptr(cnt), st)
+        grp = pw.g_enc[l]
+        PQn, hVn = new_pq(grp), torch.empty_like(hV)
+        _node_update(hV, N, lw, gsum, cnt, 0.0, mask, grp, hVn, PQn)
+        hV, PQ = hVn, PQn
+        call("mpnn_enc_edge_update", ptr(hE), ptr(PQ), PQ.shape[1], 0, H, ptr(E_idx32), ptr(lw["W11b"]),
+             ptr(lw["W12"]), ptr(lw["b12"]), ptr(lw["W13"]), ptr(lw["b13"]), ptr(lw["ln3w"]), ptr(lw["ln3b"]), B, L, K,
+             st)
+    return dict(hE=hE, hV=hV, PQ=PQ, K=K, E_idx64=E_idx64, E_idx32=E_idx32, edge_mask=edge_mask)
+
+
+def decode_levels(rank, E_idx64):
+    """Dependency level of every residue of every sample: 1 + the largest level among the neighbours that are
+    decoded earlier.  Residues of one level only read finished residues, so a level is one batched launch.
+    rank [n_samples, P, L] int64 -> (residue ids sorted by level [n_samples*P*L] int32, residues per level)."""
+    S_, P, L = rank.shape
+    K = E_idx64.shape[-1]
+    nbr = E_idx64.reshape(1, P, L * K).expand(S_, P, L * K)
+    before = torch.gather(rank, 2, nbr).view(S_, P, L, K) < rank.unsqueeze(-1)
+    level = torch.ones(S_, P, L, device=rank.device, dtype=torch.int64)
+    while True:  # monotone relaxation; 8 sweeps between host checks
+        prev = level
+        for _ in range(8):
+            level = 1 + (torch.gather(level, 2, nbr).view(S_, P, L, K) * before).amax(-1)
+        if torch.equal(level, prev):
+            break
+    flat = level.reshape(-1)
+    perm = torch.argsort(flat, stable=True).to(torch.int32)
+    return perm, torch.bincount(flat)[1:].tolist()
+
+
+def sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true=None, n_samples=1, temperature=0.1,
+           seed=0, fix_order=None, logit_bias=None, backbone_noise=None):
+    """Draw n_samples sequences per structure with a random (or given) decoding order.
+
+    Returns dict(S [n_samples,B,L] int64, log_probs [n_samples,B,L,21] (the model's log-probs at every residue, as a
+    teacher-forced forward on S with the same order returns them), order [n_samples,B,L]).  Residues with
+    chain_M * mask == 0 are not designed: they keep S_true.  The featurizer and encoder run once per structure."""
+    _require_device(X, "X")
+    dev = X.device
+    mask = _f32(mask)
+    B, L = mask.shape
+    N = B * L
+    pw = packed(model)
+    n_dec = len(pw.dec)
+    if n_dec == 0 or n_dec > 4:
+        raise ValueError("mpnn_amd.sample needs 1..4 decoder layers")
+    st = stream_ptr()
+    with torch.no_grad():
+        enc = _encode(model, X, mask, _i64(residue_idx), _i64(chain_encoding_all), backbone_noise)
+        K = enc["K"]
+        if K > 48:
+            raise NotImplementedError("mpnn_amd.sample covers k_neighbors <= 48")
+        Ns = n_samples * N
+        cm = (_f32(chain_M) * mask)
+        if fix_order is not None:
+            order = _i64(fix_order)
+            order = order.expand(n_samples, B, L).contiguous() if order.dim() == 2 else order.contiguous()
+        else:  # reference :489-491, one draw per sample
+            g_ = torch.Generator(device=dev)
+            g_.manual_seed(int(seed))
+            noise = torch.randn(n_samples, B, L, device=dev, generator=g_)
+            order = torch.argsort((cm.unsqueeze(0) + 0.0001) * torch.abs(noise), dim=-1)
+        rank = torch.zeros(Ns, device=dev, dtype=torch.int32)
+        call("mpnn_order_rank", ptr(order), n_samples * B, L, ptr(rank), st)
+        perm, counts = decode_levels(rank.view(n_samples, B, L).to(torch.int64), enc["E_idx64"])
+
+        S_in = _i64(S_true).reshape(1, N).expand(n_samples, N).contiguous() if S_true is not None else \
+            torch.zeros(n_samples, N, device=dev, dtype=torch.int64)
+        S_out = torch.zeros_like(S_in)
+        designable = cm.reshape(1, N).expand(n_samples, N).contiguous()
+        mask_s = mask.reshape(1, N).expand(n_samples, N).contiguous()
+        log_probs = torch.zeros(Ns, pw.n_letters, device=dev, dtype=torch.float32)
+        # sample-side state: layer inputs hV_l, projections [Pa_l | A_l]; encoder rows PVenc_l stay shared
+        base = 2 * H if len(pw.enc) else 0
+        PQenc = enc["PQ"]
+        hVs = [enc["hV"].repeat(n_samples, 1)] + [torch.empty(Ns, H, device=dev) for _ in range(n_dec)]
+        PA = [PQenc[:, base:base + 2 * H].repeat(n_samples, 1)] + \
+             [torch.empty(Ns, 2 * H, device=dev) for _ in range(n_dec - 1)]
+        gsum = torch.empty(Ns, H, device=dev, dtype=torch.float32)
+        import ctypes
+        A_rows = (ctypes.c_void_p * n_dec)(*[t.data_ptr() for t in PA])
+        A_ld = (ctypes.c_int * n_dec)(*([2 * H] * n_dec))
+        A_off = (ctypes.c_int * n_dec)(*([H] * n_dec))
+        lb = _f32(logit_bias).to(dev) if logit_bias is not None else None
+        start = 0
+        for cnt_l in counts:
+            nodes = perm[start:start + cnt_l]
+            start += cnt_l
+            for l, lw in enumerate(pw.dec):
+                call("mpnn_dec_message_subset", ptr(enc["hE"]), ptr(PA[l]), 2 * H, 0, ptr(PA[l]), 2 * H, H, ptr(PQenc),
+                     PQenc.shape[1], base + 2 * H + H * l, ptr(rank), ptr(enc["E_idx32"]), ptr(mask_s),
+                     ptr(enc["edge_mask"]), ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"]), nodes.data_ptr(), cnt_l, N, L,
+                     K, ptr(gsum), st)
+                grp = pw.g_dec[l]
+                call("mpnn_node_update_subset", ptr(hVs[l]), ptr(gsum), float(K), ptr(mask_s), ptr(lw["W3"]),
+                     ptr(lw["b3"]), ptr(lw["ln1w"]), ptr(lw["ln1b"]), ptr(lw["Win"]), ptr(lw["bin"]), ptr(lw["Wout"]),
+                     ptr(lw["bout"]), ptr(lw["ln2w"]), ptr(lw["ln2b"]), lw["scale"], ptr(grp[0]), ptr(grp[1]), grp[2],
+                     nodes.data_ptr(), cnt_l, ptr(hVs[l + 1]), ptr(PA[l + 1]) if grp[2] else None, st)
+            call("mpnn_sample_subset", ptr(hVs[n_dec]), ptr(pw.Wlogit), ptr(pw.blogit), ptr(lb), pw.n_letters,
+                 nodes.data_ptr(), cnt_l, float(temperature), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(designable),
+                 ptr(S_in), ptr(S_out), ptr(log_probs), ptr(pw.TS), pw.TS.shape[1], n_dec, A_rows, A_ld, A_off, st)
+    return dict(S=S_out.view(n_samples, B, L), log_probs=log_probs.view(n_samples, B, L, -1),
+                order=order.view(n_samples, B, L), n_levels=len(counts))
 
 
 def edges_to_natural(hE, n_nodes, K):

@@ -158,5 +158,15 @@ class ProteinMPNN(nn.Module):
     def forward(self, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order=None,
                 fix_backbone_noise=None):
         """Graph-conditioned sequence model: log_probs [B,L,num_letters] (reference :427-529)."""
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from . import training
+            return training.forward_train(self, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order,
+                                          fix_backbone_noise)
         return engine.forward(self, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order,
                               fix_backbone_noise)
+
+    def sample(self, X, mask, chain_M, residue_idx, chain_encoding_all, S_true=None, n_samples=1, temperature=0.1,
+               seed=0, fix_order=None, logit_bias=None):
+        """Autoregressive sampling (no counterpart in the reference; see engine.sample)."""
+        return engine.sample(self, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_samples, temperature,
+                             seed, fix_order, logit_bias)
