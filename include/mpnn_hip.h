@@ -140,12 +140,15 @@ int mpnn_message_train(int dec, const float* hE_frag, const float* P, const floa
                        const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K,
                        float* gsum, float* cnt, float* a1_frag, float* a2_frag, void* stream);
 
-/* Forward of mpnn_enc_edge_update, out of place, storing a1', a2' and the pre-LayerNorm sum z (:90-95). */
+/* Forward of mpnn_enc_edge_update, out of place, storing a1', a2' and the pre-LayerNorm sum z (:90-95).
+ * p_drop > 0 applies EncLayer.dropout3 (:94) to the MLP output: an element is kept when
+ * mix32(element_index * 0x9E3779B1 ^ drop_seed) >= p_drop * 2^32 (element_index = its float index in the fragment
+ * array) and scaled by 1 / (1 - p_drop); the backward call must be given the same p_drop and drop_seed. */
 int mpnn_enc_edge_update_train(const float* hE_frag, const float* P, const float* Q, const int32_t* E_idx32,
                                const float* W11b_packed, const float* W12_packed, const float* b12,
                                const float* W13_packed, const float* b13, const float* ln_w, const float* ln_b, int B,
                                int L, int K, float* hE_out, float* a1_frag, float* a2_frag, float* z_frag,
-                               void* stream);
+                               float p_drop, uint32_t drop_seed, void* stream);
 
 /* Backward of the message MLP: given dgsum, writes da2 (fragment), s-scaled da1 rows, dP = sum_k da1, and
  * dE (+)= W1b^T (s da1).  W2T / W1bT are mpnn_pack_linear_split of the TRANSPOSED matrices.
@@ -160,7 +163,8 @@ int mpnn_message_bwd(int dec, const float* dgsum, const float* a1_frag, const fl
 int mpnn_enc_edge_update_bwd(const float* dy_frag, const float* z_frag, const float* a2_frag, const float* a1_frag,
                              const float* ln_w, const float* W13T_packed, const float* W12T_packed,
                              const float* W11bT_packed, int B, int L, int K, float* dz_frag, float* da2_frag,
-                             float* da1_rows, float* dP, float* dE_frag, float* dln, float* amax3, void* stream);
+                             float* da1_rows, float* dP, float* dE_frag, float* dln, float* amax3, float p_drop,
+                             uint32_t drop_seed, void* stream);
 
 /* dW[fo][fi] += sum_edges A[e][fo] * f(B[e][fi]), dbias[fo] += sum_edges A[e][fo]  (the nn.Linear weight / bias
  * gradients of one per-edge 128x128 layer).  A: fragment layout, or rows when a_rows != 0; B: fragment layout,

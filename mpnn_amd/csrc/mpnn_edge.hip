@@ -230,7 +230,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
                   const float* __restrict__ b12, const h8* __restrict__ W13, const float* __restrict__ b13,
                   const float* __restrict__ ln_w, const float* __restrict__ ln_b, int N, int L,
                   f32x4* __restrict__ hE_out, f32x4* __restrict__ sv1, f32x4* __restrict__ sv2,
-                  f32x4* __restrict__ svz) {
+                  f32x4* __restrict__ svz, unsigned drop_thresh, unsigned drop_seed, float inv_keep) {
   __shared__ h8 lds[2 * WSPLIT];
   lds_fill(lds, W11b, WSPLIT);
   lds_fill(lds + WSPLIT, W12, WSPLIT);
@@ -310,11 +310,12 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #pragma unroll
         for (int c = 0; c < KT; ++c) sv2[soff + (t * KT + c) * 64] = h2[t][c];
     }
-    // residual e -> layer 3's initial accumulator (loads fly under the GELU + split of h2)
+    // residual e -> layer 3's initial accumulator (loads fly under the GELU + split of h2); the training form
+    // adds it after the dropout of the MLP output instead
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-      for (int c = 0; c < KT; ++c) h1[t][c] = x[(t * KT + c) * 64];
+      for (int c = 0; c < KT; ++c) h1[t][c] = SAVE ? f32x4{0.f, 0.f, 0.f, 0.f} : x[(t * KT + c) * 64];
     tile_to_bfrag<MPNN_NT, KT, true>(h2, hb);
     // ---- layer 3; W13 fragments (hi, lo) from L2, D steps ahead.  step q = kk * 8 + to
     {
@@ -351,7 +352,12 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #pragma unroll
       for (int c = 0; c < KT; ++c) {
         h1[t][c] += bb;
-        if (SAVE) svz[soff + (t * KT + c) * 64] = h1[t][c];
+        if (SAVE) {
+          if (drop_thresh)
+            h1[t][c] = dropout4(h1[t][c], (unsigned)(soff + (t * KT + c) * 64) * 4u, drop_seed, drop_thresh, inv_keep);
+          h1[t][c] += x[(t * KT + c) * 64];
+          svz[soff + (t * KT + c) * 64] = h1[t][c];
+        }
       }
     }
     tile_layernorm<KT>(h1, ln_w, ln_b, lane);
@@ -507,7 +513,7 @@ extern "C" int mpnn_enc_edge_update(float* hE_frag, const float* PQ, int ldpq, i
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_enc_edge_update<kKT, false>), grid, block, 0, (hipStream_t)stream,
                                      (f32x4*)hE_frag, PQ, ldpq, offP, PQ, ldpq, offQ, E_idx32, (const h8*)W11b_packed,
                                      (const h8*)W12_packed, b12, (const h8*)W13_packed, b13, ln_w, ln_b, N, L,
-                                     (f32x4*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr));
+                                     (f32x4*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr, 0u, 0u, 1.0f));
   MPNN_LAUNCH_CHECK();
 }
 
@@ -567,18 +573,22 @@ extern "C" int mpnn_enc_edge_update_train(const float* hE_frag, const float* P, 
                                           const float* W11b_packed, const float* W12_packed, const float* b12,
                                           const float* W13_packed, const float* b13, const float* ln_w,
                                           const float* ln_b, int B, int L, int K, float* hE_out, float* a1_frag,
-                                          float* a2_frag, float* z_frag, void* stream) {
+                                          float* a2_frag, float* z_frag, float p_drop, uint32_t drop_seed,
+                                          void* stream) {
   MPNN_CHECK_ARG(hE_frag && P && Q && E_idx32 && W11b_packed && W12_packed && b12 && W13_packed && b13 && ln_w &&
                      ln_b && hE_out && a1_frag && a2_frag && z_frag,
                  "mpnn_enc_edge_update_train: null pointer");
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 48 && hE_out != hE_frag,
                  "mpnn_enc_edge_update_train: bad sizes (training path covers K <= 48, out of place)");
+  MPNN_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mpnn_enc_edge_update_train: dropout probability must be in [0, 1)");
+  const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
   const int N = B * L, KT = (K + 15) / 16;
   dim3 grid(edge_grid(N, MPNN_UPD_WAVES)), block(MPNN_UPD_WAVES * 64);
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_enc_edge_update<kKT, true>), grid, block, 0, (hipStream_t)stream,
                                      (f32x4*)hE_frag, P, 128, 0, Q, 128, 0, E_idx32, (const h8*)W11b_packed,
                                      (const h8*)W12_packed, b12, (const h8*)W13_packed, b13, ln_w, ln_b, N, L,
-                                     (f32x4*)hE_out, (f32x4*)a1_frag, (f32x4*)a2_frag, (f32x4*)z_frag));
+                                     (f32x4*)hE_out, (f32x4*)a1_frag, (f32x4*)a2_frag, (f32x4*)z_frag, thresh,
+                                     (unsigned)drop_seed, 1.0f / (1.0f - p_drop)));
   MPNN_LAUNCH_CHECK();
 }
 

@@ -261,7 +261,8 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
                   const f32x4* __restrict__ a1, const float* __restrict__ ln_w, const h8* __restrict__ W13T,
                   const h8* __restrict__ W12T, const h8* __restrict__ W11bT, int N, f32x4* __restrict__ dz_out,
                   f32x4* __restrict__ da2_out, float* __restrict__ da1_nat, float* __restrict__ dP, f32x4* dE,
-                  float* __restrict__ dln, unsigned* __restrict__ amax) {
+                  float* __restrict__ dln, unsigned* __restrict__ amax, unsigned drop_thresh, unsigned drop_seed,
+                  float inv_keep) {
   __shared__ h8 lds[2 * WSPLIT];
   __shared__ float lnacc[2 * MPNN_H];
   __shared__ unsigned amax_l[3];
@@ -290,10 +291,17 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
         d[t][c] = dy[off + (t * KT + c) * 64];
       }
     tile_layernorm_bwd<KT>(x, d, ln_w, lnacc, lane);
+    // dz goes two ways: unchanged along the residual (parked in dE until the end), and through the dropout mask of
+    // the MLP output (:94) into W13^T / the W13 and b13 gradients (dz_out)
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-      for (int c = 0; c < KT; ++c) dz_out[off + (t * KT + c) * 64] = d[t][c];
+      for (int c = 0; c < KT; ++c) {
+        dE[off + (t * KT + c) * 64] = d[t][c];
+        if (drop_thresh)
+          d[t][c] = dropout4(d[t][c], (unsigned)(off + (t * KT + c) * 64) * 4u, drop_seed, drop_thresh, inv_keep);
+        dz_out[off + (t * KT + c) * 64] = d[t][c];
+      }
     BFrag db[NKK][KT];
     float un = grad_to_bfrag<KT>(d, db, &amax_l[0]);
     // ---- through W13, gelu'(a2)
@@ -324,7 +332,7 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-      for (int c = 0; c < KT; ++c) dE[off + (t * KT + c) * 64] = x[t][c] * un + dz_out[off + (t * KT + c) * 64];
+      for (int c = 0; c < KT; ++c) dE[off + (t * KT + c) * 64] = x[t][c] * un + dE[off + (t * KT + c) * 64];
   }
   __syncthreads();
   if (threadIdx.x < 2 * MPNN_H) unsafeAtomicAdd(dln + threadIdx.x, lnacc[threadIdx.x]);
@@ -577,12 +585,14 @@ extern "C" int mpnn_enc_edge_update_bwd(const float* dy_frag, const float* z_fra
                                         const float* a1_frag, const float* ln_w, const float* W13T_packed,
                                         const float* W12T_packed, const float* W11bT_packed, int B, int L, int K,
                                         float* dz_frag, float* da2_frag, float* da1_rows, float* dP, float* dE_frag,
-                                        float* dln, float* amax3, void* stream) {
+                                        float* dln, float* amax3, float p_drop, uint32_t drop_seed, void* stream) {
   MPNN_CHECK_ARG(dy_frag && z_frag && a2_frag && a1_frag && ln_w && W13T_packed && W12T_packed && W11bT_packed &&
                      dz_frag && da2_frag && da1_rows && dP && dE_frag && dln && amax3,
                  "mpnn_enc_edge_update_bwd: null pointer");
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 48,
                  "mpnn_enc_edge_update_bwd: bad sizes (training path covers K <= 48)");
+  MPNN_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mpnn_enc_edge_update_bwd: dropout probability must be in [0, 1)");
+  const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
   const int N = B * L, KT = (K + 15) / 16;
   dim3 grid(edge_grid(N, MPNN_BWD_WAVES)), block(MPNN_BWD_WAVES * 64);
   KT_DISPATCH(KT > 3 ? 3 : KT,
@@ -590,7 +600,8 @@ extern "C" int mpnn_enc_edge_update_bwd(const float* dy_frag, const float* z_fra
                                  (const f32x4*)dy_frag, (const f32x4*)z_frag, (const f32x4*)a2_frag,
                                  (const f32x4*)a1_frag, ln_w, (const h8*)W13T_packed, (const h8*)W12T_packed,
                                  (const h8*)W11bT_packed, N, (f32x4*)dz_frag, (f32x4*)da2_frag, da1_rows, dP,
-                                 (f32x4*)dE_frag, dln, (unsigned*)amax3));
+                                 (f32x4*)dE_frag, dln, (unsigned*)amax3, thresh, (unsigned)drop_seed,
+                                 1.0f / (1.0f - p_drop)));
   MPNN_LAUNCH_CHECK();
 }
 

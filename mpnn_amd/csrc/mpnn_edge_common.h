@@ -18,6 +18,25 @@ __device__ __forceinline__ f32x4 row_tile(const float* row, int t) {
   return *reinterpret_cast<const f32x4*>(row + 16 * t);
 }
 
+// Dropout keep-decision of one fragment-layout element (training; reference EncLayer.dropout3, :94).  Counter-based:
+// the same (seed, element id) gives the same decision in the forward and the backward kernel, nothing is stored.
+// element id = ((node * 8 + t) * KT + c) * 256 + lane * 4 + r  (its float index in the fragment array, mod 2^32)
+__device__ __forceinline__ bool dropout_keep(unsigned id, unsigned seed, unsigned thresh) {
+  unsigned h = (id * 0x9E3779B1u) ^ seed;
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h >= thresh;  // thresh = p * 2^32
+}
+__device__ __forceinline__ f32x4 dropout4(f32x4 v, unsigned id0, unsigned seed, unsigned thresh, float inv_keep) {
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = dropout_keep(id0 + r, seed, thresh) ? v[r] * inv_keep : 0.f;
+  return o;
+}
+
 constexpr int NKK = MPNN_NT / 2;       // k-steps (32 features) per 128-wide layer
 constexpr int WSPLIT = 8 * NKK * 2 * 64;  // h8 elements of one packed 128x128 matrix (64 KiB)
 

@@ -223,7 +223,7 @@ class EdgeUpdateFn(torch.autograd.Function):
     """e' = LN3(e + W13 gelu(W12 gelu(P'_i + Q'_j + W11b e) + b12) + b13)   (mpnn_edge.hip k_enc_edge_update)."""
 
     @staticmethod
-    def forward(ctx, g, slot, hE, P, Q, W11b, W12, b12, W13, b13, lnw, lnb):
+    def forward(ctx, g, slot, p_drop, seed, hE, P, Q, W11b, W12, b12, W13, b13, lnw, lnb):
         dev = hE.device
         P, Q = P.contiguous(), Q.contiguous()
         out = torch.empty_like(hE)
@@ -232,8 +232,8 @@ class EdgeUpdateFn(torch.autograd.Function):
         w1p, w2p, w3p = _pack_split(W11b), _pack_split(W12), _pack_split(W13)
         call("mpnn_enc_edge_update_train", ptr(hE), ptr(P), ptr(Q), ptr(g.E_idx32), ptr(w1p),
              ptr(w2p), ptr(vec[0]), ptr(w3p), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), g.B, g.L,
-             g.K, ptr(out), ptr(a1), ptr(a2), ptr(z), stream_ptr())
-        ctx.g, ctx.slot = g, slot
+             g.K, ptr(out), ptr(a1), ptr(a2), ptr(z), float(p_drop), int(seed), stream_ptr())
+        ctx.g, ctx.slot, ctx.drop = g, slot, (float(p_drop), int(seed))
         ctx.save_for_backward(hE, a1, a2, z, W11b, W12, W13, lnw)
         return out
 
@@ -253,12 +253,12 @@ class EdgeUpdateFn(torch.autograd.Function):
         w3t, w2t, w1t = _pack_split(W13.detach().t()), _pack_split(W12.detach().t()), _pack_split(W11b.detach().t())
         call("mpnn_enc_edge_update_bwd", ptr(dy), ptr(z), ptr(a2), ptr(a1), ptr(lnw.detach().contiguous()),
              ptr(w3t), ptr(w2t), ptr(w1t),
-             g.B, g.L, g.K, ptr(dz), ptr(da2), ptr(rows), ptr(dP), ptr(dE), ptr(dln), ptr(amax), stream_ptr())
+             g.B, g.L, g.K, ptr(dz), ptr(da2), ptr(rows), ptr(dP), ptr(dE), ptr(dln), ptr(amax), ctx.drop[0], ctx.drop[1], stream_ptr())
         dQ, _ = _gather(rows, g, None)
         dW13, db13 = _wgrad(dz, False, amax[0:1], a2, True, g, True)
         dW12, db12 = _wgrad(da2, False, amax[1:2], a1, True, g, True)
         dW11b, _ = _wgrad(rows, True, amax[2:3], hE, False, g, False)
-        return None, None, dE, dP, dQ, dW11b, dW12, db12, dW13, db13, dln[:H], dln[H:]
+        return None, None, None, None, dE, dP, dQ, dW11b, dW12, db12, dW13, db13, dln[:H], dln[H:]
 
 
 class FromNaturalFn(torch.autograd.Function):
@@ -357,9 +357,7 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
     fm = model.features
     training = model.training
     p_drop = float(model.dropout_p)
-    if p_drop > 0 and training and len(model.encoder_layers):
-        raise NotImplementedError("mpnn_amd training: edge-level dropout (EncLayer.dropout3) is not built yet; "
-                                  "construct the model with dropout=0.0")
+    p_edge = p_drop if training else 0.0
     _ZEROS.reset(dev)  # gradient accumulators of this step's backward pass
     with torch.no_grad():
         atoms, _, E_idx64, E_idx32, _, edge_mask, K = engine._geometry(fm, X, mask, fix_backbone_noise, training)
@@ -382,7 +380,8 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
         gsum, cnt = MessageFn.apply(g, slot, False, hE, P, Q, None, W1[:, H:2 * H], lyr.W2.weight, lyr.W2.bias)
         hV = _node_tail(lyr, hV, gsum, cnt, mcol, p_drop, training)
         P, Q = linear(hV, W11[:, :H], lyr.W11.bias), linear(hV, W11[:, 2 * H:])
-        hE = EdgeUpdateFn.apply(g, slot, hE, P, Q, W11[:, H:2 * H], lyr.W12.weight, lyr.W12.bias, lyr.W13.weight,
+        drop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_edge > 0 else 0  # host generator: no sync
+        hE = EdgeUpdateFn.apply(g, slot, p_edge, drop_seed, hE, P, Q, W11[:, H:2 * H], lyr.W12.weight, lyr.W12.bias, lyr.W13.weight,
                                 lyr.W13.bias, lyr.norm3.weight, lyr.norm3.bias)
         slot = GradSlot()
 

@@ -15,11 +15,11 @@ T = torch.from_numpy
 GRAD_RTOL = 1e-3
 
 
-def build(kw, device="cuda"):
+def build(kw, device="cuda", dropout=0.0, augment_eps=0.0):
     import mpnn_amd
     from mpnn_amd.synthetic import fill_parameters_
 
-    model = mpnn_amd.ProteinMPNN(augment_eps=0.0, dropout=0.0, **kw).train()
+    model = mpnn_amd.ProteinMPNN(augment_eps=augment_eps, dropout=dropout, **kw).train()
     fill_parameters_(model, seed=0)
     return model.to(device)
 
@@ -152,20 +152,95 @@ def test_wgrad_and_gather_kernels():
     assert float((outB.double() - wantB).abs().max()) < 1e-4
 
 
-def test_train_steps_reduce_loss():
-    """Five AdamW steps on one synthetic batch: finite, decreasing loss; weights stay finite (train.py:375-392)."""
+@pytest.mark.parametrize("dropout,augment_eps", [(0.0, 0.0), (0.1, 0.1)])
+def test_train_steps_reduce_loss(dropout, augment_eps):
+    """Eight AdamW steps on one synthetic batch through ProteinMPNN.forward in training mode (the reference's defaults
+    dropout = 0.1, augment_eps = 0.1 included): finite, decreasing loss; weights stay finite (train.py:375-392)."""
     from mpnn_amd import training
     from mpnn_amd.synthetic import synthetic_batch
 
+    torch.manual_seed(0)
     b = synthetic_batch(B=4, L=96, seed=21, lengths=[96, 80, 64, 50], n_chains=2, design_fraction=0.8)
-    model = build(dict(k_neighbors=48))
+    model = build(dict(k_neighbors=48), dropout=dropout, augment_eps=augment_eps)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2)
     d = "cuda"
     batch = tuple(b[k].to(d) for k in ("X", "S", "mask", "chain_M", "residue_idx", "chain_encoding_all"))
     losses = []
-    for _ in range(5):
+    for _ in range(8):
         loss, _ = training.train_step(model, opt, batch, fix_order=b["fix_order"].to(d))
         losses.append(float(loss))
     assert all(np.isfinite(losses)), losses
-    assert losses[-1] < losses[0], losses
+    assert min(losses[-2:]) < losses[0], losses
     assert all(torch.isfinite(p).all() for p in model.parameters())
+    # the nn.Module surface takes the same path: forward in training mode returns a differentiable tensor
+    lp = model(*batch, fix_order=b["fix_order"].to(d))
+    assert lp.requires_grad and lp.shape == (4, 96, 21)
+
+
+def _dropout_keep_mask(N, K, p, seed, device):
+    """The kernels' counter-based keep decision (mpnn_edge_common.h dropout_keep), replicated with integer tensor ops:
+    element id = ((node * 8 + t) * KT + c) * 256 + (16 g + col) * 4 + r for edge e = 16 c + col, feature f = 16 t + 4 g + r."""
+    KT = (K + 15) // 16
+    node = torch.arange(N, device=device).view(N, 1, 1)
+    e = torch.arange(K, device=device).view(1, K, 1)
+    f = torch.arange(128, device=device).view(1, 1, 128)
+    t, g, r = f // 16, (f % 16) // 4, f % 4
+    c, col = e // 16, e % 16
+    M = 0xFFFFFFFF
+    idx = (((node * 8 + t) * KT + c) * 256 + (16 * g + col) * 4 + r) & M
+    h = ((idx * 0x9E3779B1) & M) ^ seed
+    h = h ^ (h >> 16)
+    h = (h * 0x85EBCA6B) & M
+    h = h ^ (h >> 13)
+    h = (h * 0xC2B2AE35) & M
+    h = h ^ (h >> 16)
+    return h >= int(p * 4294967296.0)
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1, 0.5])
+def test_edge_update_with_dropout_vs_aten(p_drop):
+    """EncLayer edge update with dropout3 (:90-95): forward value and every gradient of the HIP Function against the
+    same maths in ATen with the same keep mask; the dropped fraction is p."""
+    import torch.nn.functional as F
+    from mpnn_amd import engine, training
+
+    torch.manual_seed(3)
+    d = "cuda"
+    B, L, K, seed = 2, 37, 40, 12345
+    N = B * L
+    E_idx = torch.stack([torch.stack([torch.randperm(L)[:K] if K <= L else torch.randint(0, L, (K,)) for _ in range(L)])
+                         for _ in range(B)]).to(d)
+    Kp = 48
+    idx32 = torch.zeros(N, Kp, dtype=torch.int32, device=d)
+    idx32[:, :K] = E_idx.reshape(N, K).to(torch.int32)
+    g = training.Graph(E_idx, idx32.reshape(-1).contiguous(), torch.ones(N, device=d), None, K)
+    leaf = lambda *s, sc=1.0: (sc * torch.randn(*s, device=d)).requires_grad_(True)
+    hE_nat, P, Q = leaf(N, K, 128), leaf(N, 128), leaf(N, 128)
+    W11b, W12, W13 = leaf(128, 128, sc=0.09), leaf(128, 128, sc=0.09), leaf(128, 128, sc=0.09)
+    b12, b13, lnw, lnb = leaf(128, sc=0.1), leaf(128, sc=0.1), leaf(128), leaf(128, sc=0.1)
+    params = [hE_nat, P, Q, W11b, W12, b12, W13, b13, lnw, lnb]
+    upstream = torch.randn(N, K, 128, device=d) * 1e-4   # gradient-sized, like a real backward pass
+
+    training._ZEROS.reset(torch.device(d, torch.cuda.current_device()))
+    hE = training.FromNaturalFn.apply(g, hE_nat)
+    out = training.EdgeUpdateFn.apply(g, training.GradSlot(), p_drop, seed, hE, P, Q, W11b, W12, b12, W13, b13, lnw, lnb)
+    out_nat = engine.edges_to_natural(out.detach(), N, K)
+    (engine.edges_to_natural(out, N, K) if False else out).backward(engine.edges_from_natural(upstream, N, K))
+    got = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+
+    keep = _dropout_keep_mask(N, K, p_drop, seed, d) if p_drop > 0 else torch.ones(N, K, 128, dtype=torch.bool, device=d)
+    if p_drop > 0:
+        assert abs(1.0 - keep.float().mean().item() - p_drop) < 0.01
+    dest = g.dest.view(N, K)
+    a1 = P.unsqueeze(1) + Q[dest] + F.linear(hE_nat, W11b)
+    msg = F.linear(F.gelu(F.linear(F.gelu(a1), W12, b12)), W13, b13)
+    msg = msg * keep / (1.0 - p_drop)
+    want = F.layer_norm(hE_nat + msg, (128,), lnw, lnb, 1e-5)
+    assert float((out_nat - want).abs().max()) < 2e-5
+    want.backward(upstream)
+    names = "hE P Q W11b W12 b12 W13 b13 ln_w ln_b".split()
+    for n, a, p in zip(names, got, params):
+        err = float((a.double() - p.grad.double()).norm() / (p.grad.double().norm() + 1e-30))
+        assert err < 1e-4, f"d{n}: relative error {err:.2e}"
