@@ -121,6 +121,47 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
                     "and optimizer run as ATen ops this round (remaining time = ms_per_step - hip_kernels_total_ms)"}
 
 
+def sampling_leg(a, dev, rank, world, dist, barrier):
+    """BASELINE configs[4]: autoregressive sampling, random decoding order, virtual-centre node; 64 samples of one
+    L=512 structure, sharded over the ranks (each rank encodes the structure once and draws its share)."""
+    from mpnn_amd import ProteinMPNN
+    from mpnn_amd.synthetic import synthetic_batch
+
+    L, K = a.length, a.k
+    total = a.samples
+    mine = total // world + (1 if rank < total % world else 0)
+    torch.manual_seed(1234)
+    model = ProteinMPNN(k_neighbors=K, augment_eps=0.0, dropout=0.0, use_virtual_center=True).eval().to(dev)
+    b = synthetic_batch(1, L, seed=3000, device=dev)  # the same structure on every rank
+    args = (b["X"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
+    iters = 3
+
+    def step(i):
+        return model.sample(*args, n_samples=max(mine, 1), temperature=0.1, seed=100 * i + rank)
+
+    out = step(0)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        out = step(i + 1)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the job's product: every rank's sequences gathered on all ranks (the path's only collective)
+        gathered = [torch.empty_like(out["S"]) for _ in range(world)] if mine * world == total else None
+        if gathered is not None:
+            dist.all_gather(gathered, out["S"].contiguous())
+    assert int(out["S"].min()) >= 0 and torch.isfinite(out["log_probs"]).all()
+    return {"metric": "sampled residues/sec (autoregressive, random order, virtual centre) at L=512,k=48",
+            "value": round(total * L * iters / elapsed, 1), "unit": "residues/s", "n_gpus": world, "steps": iters,
+            "ms_per_step": round(elapsed / iters * 1e3, 3), "scaling": "strong",
+            "config": {"workload": f"BASELINE configs[4]: 1 structure x L={L}, k={K}, {total} samples "
+                                   f"({mine} on rank 0), temperature 0.1", "dependency_levels": out["n_levels"]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +173,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-batch", type=int, default=20,
                     help="proteins per rank in the training leg (BASELINE configs[2]: ~10k-residue batches); 0 = skip")
+    ap.add_argument("--samples", type=int, default=64,
+                    help="sequences drawn per structure in the sampling leg (BASELINE configs[4]); 0 = skip")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -220,6 +263,10 @@ def main():
     if a.train_batch > 0:
         train = train_leg(a, dev, rank, world, dist, barrier, _lib)
 
+    sampling = None
+    if a.samples > 0:
+        sampling = sampling_leg(a, dev, rank, world, dist, barrier)
+
     if rank == 0:
         total_res = B * L * world * a.steps
         value = total_res / elapsed
@@ -237,6 +284,8 @@ def main():
         }
         if train is not None:
             line["train_step"] = train
+        if sampling is not None:
+            line["sampling"] = sampling
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(2, L, K, iters=3)
         print(json.dumps(line), flush=True)
