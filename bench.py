@@ -244,12 +244,23 @@ def main():
     dominant = max(per_kernel, key=lambda n: per_kernel[n]["ms_per_step"])
     dk = per_kernel[dominant]
     roofline = None
+    traffic = None
+    try:  # HBM bytes per launch from the committed PMC passes (same workload only); see profiles/r01_pmc_traffic.txt
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if pm["workload"] == {"B": B, "L": L, "K": K} and dominant in pm["kernels"]:
+            kk = pm["kernels"][dominant]
+            traffic = {"bytes_per_launch": int((2 * kk["FETCH_SIZE_KB"] + kk["WRITE_SIZE_KB"]) * 1024),
+                       "algorithmic_bytes_per_launch": 2 * B * L * 8 * ((K + 15) // 16) * 1024 if "update" in dominant
+                       else B * L * 8 * ((K + 15) // 16) * 1024,
+                       "source": pm["source"], "correction": pm["correction"]}
+    except (OSError, KeyError, ValueError):
+        pass
     if dominant in FLOP_AS_WRITTEN:
         sec = dk["avg_ms"] * 1e-3
         ach = FLOP_F16_ISSUED[dominant] * B * L / sec / 1e12
         asw = FLOP_AS_WRITTEN[dominant] * B * L / sec / 1e12
         roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": PEAK_F16_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_ms": round(dk["avg_ms"], 4),
                     "as_written_f32_tflops": round(asw, 2),
                     "as_written_vs_f32_mfma_peak": round(asw / PEAK_F32_MFMA_TFLOPS, 4),
