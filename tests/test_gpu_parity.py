@@ -208,3 +208,20 @@ def test_c2_shape_property_and_checksum():
     assert (lp.argmax(-1).numpy() == z["lp_argmax"]).mean() > 0.999
     # log-probs normalise
     assert_close(torch.logsumexp(lp.double(), -1).numpy(), np.zeros((4, 512)), 0, 1e-5, "normalisation")
+
+
+def test_large_complex_L4096_vs_oracle():
+    """BASELINE configs[3] shape: one L=4096 complex, k=48 (neighbour search and gathers dominate).  Neighbour indices
+    and causal masks bit-exact, log-probs to the fp32 bar, against the oracle on the same input."""
+    from mpnn_amd.synthetic import synthetic_batch
+
+    kw = dict(k_neighbors=48)
+    model = build_model(kw)
+    b = synthetic_batch(B=1, L=4096, seed=77, n_chains=6, design_fraction=0.6)
+    rec = {n: v.numpy() for n, v in b.items()}
+    out = run_hip(model, rec)
+    ref = run_oracle(model, kw, rec)
+    same(out["E_idx"].cpu().numpy(), ref["E_idx"].numpy(), "E_idx")
+    same(out["D_neighbors"].cpu().numpy(), ref["D_neighbors"].numpy(), "D_neighbors")
+    same(out["mask_bw"].cpu().numpy(), ref["mask_bw"].numpy(), "mask_bw")
+    assert_close(out["log_probs"].cpu().numpy(), ref["log_probs"].numpy(), LP_RTOL, LP_ATOL, "log_probs")
