@@ -608,3 +608,59 @@ def enc_layer_standalone(layer, h_V, h_E, E_idx, mask_V=None, mask_attend=None):
     call("mpnn_enc_edge_update", ptr(hE), ptr(PQ2), 2 * H, 0, H, ptr(idx32), ptr(c["W11b"]), ptr(c["W12"]),
          ptr(c["b12"]), ptr(c["W13"]), ptr(c["b13"]), ptr(c["ln3w"]), ptr(c["ln3b"]), B, L, K, st)
     return hVn.view(B, L, H), edges_to_natural(hE, N, K).view(B, L, K, H)
+
+
+# ---------------------------------------------------------------------------
+# stand-alone DecLayer surface (reference :118-138): h_ESV materialised by the caller, natural layouts
+# ---------------------------------------------------------------------------
+def dec_layer_standalone(layer, h_V, h_ESV, mask_V=None, mask_attend=None):
+    """The fused decoder inside ProteinMPNN.forward never materialises h_ESV; this entry serves callers that do.
+    W1 [h_V_i | h_ESV_ik] = (W1a h_V_i + b1) + W1r h_ESV_ik: the per-edge term is one plain library GEMM
+    ([B L K, 384] x [384, 128]); its result takes the place of the edge tensor in the message kernel (identity as
+    the per-edge weight, no gathered row), then the shared node kernel finishes the layer."""
+    _require_device(h_V, "h_V")
+    dev = h_V.device
+    B, L, K, C = h_ESV.shape
+    N = B * L
+    st = stream_ptr()
+    if K > 64 or C != layer.W1.weight.shape[1] - H:
+        raise ValueError("DecLayer: h_ESV must be [B, L, K <= 64, num_in]")
+    key = tuple((p.data_ptr(), p._version) for p in layer.parameters())
+    c = getattr(layer, "_packed", None)
+    if c is None or c["key"] != key:
+        def pack_split(W, col0=0, ncols=None):
+            W = _f32(W)
+            out_f, ld = W.shape
+            ncols = ld - col0 if ncols is None else ncols
+            out = torch.empty(((out_f + 15) // 16) * ((ncols + 31) // 32) * 512, device=dev, dtype=torch.float32)
+            call("mpnn_pack_linear_split", ptr(W), out_f, ncols, ld, col0, 0, ptr(out), st)
+            return out
+        c = dict(key=key, g1=(pack_split(layer.W1.weight, 0, H), _f32(layer.W1.bias), 1),
+                 eye=pack_split(torch.eye(H, device=dev)), Wr=_f32(layer.W1.weight[:, H:]),
+                 W2=pack_split(layer.W2.weight), b2=_f32(layer.W2.bias), W3=pack_split(layer.W3.weight),
+                 b3=_f32(layer.W3.bias), ln1w=_f32(layer.norm1.weight), ln1b=_f32(layer.norm1.bias),
+                 ln2w=_f32(layer.norm2.weight), ln2b=_f32(layer.norm2.bias), Win=pack_split(layer.dense.W_in.weight),
+                 bin=_f32(layer.dense.W_in.bias),
+                 Wout=torch.cat([pack_split(layer.dense.W_out.weight, H * q, H) for q in range(4)]),
+                 bout=_f32(layer.dense.W_out.bias), scale=float(layer.scale))
+        layer._packed = c
+    hV = _f32(h_V).view(N, H)
+    X = torch.matmul(_f32(h_ESV).view(N * K, C), c["Wr"].t())            # per-edge W1r h_ESV
+    hE = edges_from_natural(X.view(N, K, H), N, K)
+    Kp = 16 * ((K + 15) // 16)
+    idx32 = torch.arange(L, device=dev, dtype=torch.int32).view(1, L, 1).expand(B, L, Kp).contiguous()  # rows unused
+    ones = torch.ones(N, device=dev, dtype=torch.float32)
+    m_att = _f32(mask_attend) if mask_attend is not None else None
+    m_V = _f32(mask_V).reshape(N) if mask_V is not None else ones
+    PQ = torch.empty(N, 2 * H, device=dev, dtype=torch.float32)
+    PQ[:, H:] = 0.0                                                      # the "gathered row" is zero here
+    P = torch.empty(N, H, device=dev, dtype=torch.float32)
+    _node_update(hV, N, None, None, None, 0.0, None, c["g1"], None, P)
+    PQ[:, :H] = P
+    gsum = torch.empty(N, H, device=dev, dtype=torch.float32)
+    cnt = torch.empty(N, device=dev, dtype=torch.float32)
+    call("mpnn_enc_message", ptr(hE), ptr(PQ), 2 * H, 0, H, ptr(idx32), ptr(ones), ptr(m_att), ptr(c["eye"]),
+         ptr(c["W2"]), ptr(c["b2"]), B, L, K, ptr(gsum), ptr(cnt), st)
+    hVn = torch.empty_like(hV)
+    _node_update(hV, N, c, gsum, cnt, 0.0, m_V, (None, None, 0), hVn, None)
+    return hVn.view(B, L, H)

@@ -83,9 +83,8 @@ class DecLayer(nn.Module):
         self.dense = PositionWiseFeedForward(num_hidden, num_hidden * 4)
 
     def forward(self, h_V, h_E, mask_V=None, mask_attend=None):
-        raise NotImplementedError(
-            "stand-alone DecLayer.forward on a materialised h_ESV is not built yet; "
-            "use ProteinMPNN.forward (fused decoder)")
+        """h_V [B,L,128], h_E = h_ESV [B,L,K,384] -> h_V, as the reference (:118-138)."""
+        return engine.dec_layer_standalone(self, h_V, h_E, mask_V, mask_attend)
 
 
 class ProteinFeatures(nn.Module):

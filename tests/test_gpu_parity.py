@@ -185,6 +185,26 @@ def test_enc_layer_surface():
     assert_close(he.cpu().numpy(), re.numpy(), 1e-4, 5e-5, "h_E")
 
 
+@pytest.mark.parametrize("K,with_masks", [(48, True), (30, False), (64, True)])
+def test_dec_layer_surface(K, with_masks):
+    """DecLayer.forward(h_V, h_ESV, mask_V, mask_attend) on a materialised h_ESV (reference :118-138)."""
+    from oracle import mpnn_oracle as orc
+
+    model = build_model(dict(k_neighbors=48))
+    g = torch.Generator().manual_seed(1)
+    B, L = 2, 53
+    h_V = torch.randn(B, L, 128, generator=g)
+    h_ESV = torch.randn(B, L, K, 384, generator=g)
+    mask_V = (torch.rand(B, L, generator=g) > 0.2).float() if with_masks else None
+    m_att = (torch.rand(B, L, K, generator=g) > 0.3).float() if with_masks else None
+    layer = model.decoder_layers[2]
+    with torch.no_grad():
+        hv = layer(h_V.cuda(), h_ESV.cuda(), mask_V.cuda() if with_masks else None, m_att.cuda() if with_masks else None)
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        rv = orc.dec_layer(sd, "decoder_layers.2", orc.Config(), h_V, h_ESV, mask_V, m_att)
+    assert_close(hv.cpu().numpy(), rv.numpy(), 1e-4, 5e-5, "h_V")
+
+
 def test_c2_shape_property_and_checksum():
     """C2 shape (L=512, K=48): checksum record from the reference + permutation-equivariance over the
     batch axis (proteins are independent), at B=8."""
