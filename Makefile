@@ -4,7 +4,8 @@ ARCH  ?= gfx950
 CSRC  := mpnn_amd/csrc
 OUT   := mpnn_amd/libmpnn_hip.so
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wno-unused-result $(EXTRA)
-OBJS  := $(CSRC)/mpnn_featurizer.o $(CSRC)/mpnn_edge.o $(CSRC)/mpnn_edge_bwd.o $(CSRC)/mpnn_node.o $(CSRC)/mpnn_node_bwd.o $(CSRC)/mpnn_abi.o
+OBJS  := $(CSRC)/mpnn_featurizer.o $(CSRC)/mpnn_edge.o $(CSRC)/mpnn_edge_bwd.o $(CSRC)/mpnn_node.o $(CSRC)/mpnn_node_bwd.o $(CSRC)/mpnn_abi.o \
+         $(CSRC)/mpnn_featurizer_f16.o $(CSRC)/mpnn_edge_f16.o $(CSRC)/mpnn_node_f16.o
 
 all: $(OUT)
 
@@ -34,3 +35,13 @@ $(CSRC)/mpnn_node.o: $(CSRC)/mpnn_node.hip $(CSRC)/mpnn_common.h
 
 $(CSRC)/mpnn_node_bwd.o: $(CSRC)/mpnn_node_bwd.hip $(CSRC)/mpnn_common.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+# second compilation of the forward kernels with one f16 product per fp32 product (entry points *_f16)
+$(CSRC)/mpnn_featurizer_f16.o: $(CSRC)/mpnn_featurizer.hip $(CSRC)/mpnn_common.h
+	$(HIPCC) $(HIPFLAGS) -DMPNN_FAST -ffp-contract=off -c $< -o $@
+
+$(CSRC)/mpnn_edge_f16.o: $(CSRC)/mpnn_edge.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h
+	$(HIPCC) $(HIPFLAGS) -DMPNN_FAST -c $< -o $@
+
+$(CSRC)/mpnn_node_f16.o: $(CSRC)/mpnn_node.hip $(CSRC)/mpnn_common.h
+	$(HIPCC) $(HIPFLAGS) -DMPNN_FAST -c $< -o $@

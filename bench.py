@@ -270,6 +270,27 @@ def main():
                             "The kernel is VALU-issue bound (GELU + f16 splitting do not co-issue with MFMA here), "
                             "see DESIGN.md section 4"}
 
+    # ---- secondary: reduced-precision forward (one f16 product per fp32 product), same workload and the L=4096 shape
+    f16 = {}
+    for tag, (Bq, Lq) in {"B%dxL%d" % (B, L): (B, L), "B4xL4096": (4, 4096)}.items():
+        bq = b if (Bq, Lq) == (B, L) else synthetic_batch(Bq, Lq, seed=4000 + rank, device=dev)
+        aq = (bq["X"], bq["S"], bq["mask"], bq["chain_M"], bq["residue_idx"], bq["chain_encoding_all"])
+        res = {}
+        for mode in ("fp32", "f16"):
+            model.set_precision(mode)
+            with torch.no_grad():
+                for _ in range(2):
+                    o = model(*aq, fix_order=bq["fix_order"])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    o = model(*aq, fix_order=bq["fix_order"])
+                torch.cuda.synchronize()
+            res[mode] = (Bq * Lq * 5 / (time.perf_counter() - t1), o)
+        model.set_precision("fp32")
+        f16[tag] = {"residues_per_s_fp32": round(res["fp32"][0], 1), "residues_per_s_f16": round(res["f16"][0], 1),
+                    "max_abs_dlogp": round(float((res["f16"][1] - res["fp32"][1]).abs().max()), 5)}
+
     train = None
     if a.train_batch > 0:
         train = train_leg(a, dev, rank, world, dist, barrier, _lib)
@@ -293,6 +314,8 @@ def main():
             "roofline": roofline,
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(per_kernel.items())},
         }
+        line["forward_f16_products"] = dict(f16, note="per-rank; one f16 MFMA product per fp32 product instead of three; "
+                                            "fp32 accumulate / GELU / LayerNorm; tolerance in include/mpnn_hip.h")
         if train is not None:
             line["train_step"] = train
         if sampling is not None:

@@ -244,6 +244,53 @@ int mpnn_sample_subset(const float* hV, const float* Wout_packed, const float* b
                        const float* TS, int ld_ts, int n_layers, float* const* A_rows, const int* A_ld,
                        const int* A_off, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Reduced-precision forward ("f16 products"; BASELINE configs[3] asks for bf16-class message MLPs): the same
+ * kernels compiled with ONE f16 MFMA product per fp32 product (operands rounded to f16, 11 significant bits - three
+ * more than bf16) instead of three; accumulation, GELU, LayerNorm, softmax stay fp32, neighbour search and masks are
+ * the exact kernels.  Same arguments and packed-weight buffers as the entry points they shadow.
+ * Stated tolerance (tests/test_gpu_parity.py): max |d log_prob| <= 5e-2, argmax agreement >= 99 %.
+ * ------------------------------------------------------------------------------------------------------------ */
+int mpnn_edge_features_f16(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
+                       const int64_t* chain_labels, const float* pos_table, const float* rbf_mu,
+                       const float* Wemb_packed, const float* ln_w, const float* ln_b, const float* We_packed,
+                       const float* We_bias, int B, int L, int K, int n_atoms, float* E_natural, float* hE_frag,
+                       void* stream);
+
+int mpnn_enc_message_f16(const float* hE_frag, const float* PQ, int ldpq, int offP, int offQ, const int32_t* E_idx32,
+                     const float* mask, const float* edge_mask, const float* W1b_packed, const float* W2_packed,
+                     const float* b2, int B, int L, int K, float* gsum, float* cnt, void* stream);
+
+int mpnn_enc_edge_update_f16(float* hE_frag, const float* PQ, int ldpq, int offP, int offQ, const int32_t* E_idx32,
+                         const float* W11b_packed, const float* W12_packed, const float* b12,
+                         const float* W13_packed, const float* b13, const float* ln_w, const float* ln_b, int B,
+                         int L, int K, void* stream);
+
+int mpnn_dec_message_f16(const float* hE_frag, const float* PQ, int ldpq, int offPa, int offA, const float* PVenc,
+                     int ldenc, int offEnc, const int32_t* rank, const int32_t* E_idx32, const float* mask,
+                     const float* edge_mask, const float* W1b_packed, const float* W2_packed, const float* b2, int B,
+                     int L, int K, float* gsum, void* stream);
+
+int mpnn_node_update_f16(const float* hV_in, const float* gsum, const float* cnt, float cnt_const, const float* mask,
+                     const float* W3_packed, const float* b3, const float* ln1_w, const float* ln1_b,
+                     const float* Win_packed, const float* b_in, const float* Wout_packed, const float* b_out,
+                     const float* ln2_w, const float* ln2_b, float scale, int do_update, const float* Wproj_packed,
+                     const float* bproj, int nproj, const float* add_table, int ld_table, int off_table,
+                     const int64_t* add_idx, int add_block, int n_nodes, float* hV_out, float* PQ, void* stream);
+
+int mpnn_dec_message_subset_f16(const float* hE_frag, const float* P, int ldp, int offP, const float* RowA, int lda,
+                            int offA, const float* PVenc, int ldenc, int offEnc, const int32_t* rank,
+                            const int32_t* E_idx32, const float* mask, const float* edge_mask, const float* W1b_packed,
+                            const float* W2_packed, const float* b2, const int32_t* node_list, int n_list,
+                            int enc_nodes, int L, int K, float* gsum, void* stream);
+
+int mpnn_node_update_subset_f16(const float* hV_in, const float* gsum, float cnt_const, const float* mask,
+                            const float* W3_packed, const float* b3, const float* ln1_w, const float* ln1_b,
+                            const float* Win_packed, const float* b_in, const float* Wout_packed, const float* b_out,
+                            const float* ln2_w, const float* ln2_b, float scale, const float* Wproj_packed,
+                            const float* bproj, int nproj, const int32_t* node_list, int n_list, float* hV_out,
+                            float* PQ, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

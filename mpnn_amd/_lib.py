@@ -55,7 +55,27 @@ SIGNATURES = {
     "mpnn_node_wgrad": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P],
 }
 
+# reduced-precision twins (one f16 product per fp32 product) of the forward entry points: same signatures
+F16_ENTRIES = ("mpnn_edge_features", "mpnn_enc_message", "mpnn_enc_edge_update", "mpnn_dec_message", "mpnn_node_update",
+               "mpnn_dec_message_subset", "mpnn_node_update_subset")
+for _n in F16_ENTRIES:
+    SIGNATURES[_n + "_f16"] = SIGNATURES[_n]
+
 _lib = None
+_suffix = ""
+
+
+def set_precision(mode: str):
+    """'fp32' (default: 3 f16 products per fp32 product, fp32-class) or 'f16' (1 product) for the forward kernels."""
+    global _suffix
+    if mode not in ("fp32", "f16"):
+        raise ValueError("precision must be 'fp32' or 'f16'")
+    _suffix = "_f16" if mode == "f16" else ""
+
+
+def entry(name: str) -> str:
+    """Entry-point name under the current precision mode."""
+    return name + _suffix if _suffix and name in F16_ENTRIES else name
 
 
 def load() -> ctypes.CDLL:
@@ -106,6 +126,7 @@ def set_profiler(store):
 
 def call(name: str, *args):
     lib = load()
+    name = entry(name)
     if _profile is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

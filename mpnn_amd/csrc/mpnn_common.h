@@ -29,6 +29,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MPNN_NT 8           // 16-row tiles per 128 features
 #define MPNN_LN_EPS 1e-5f
 
+// MPNN_FAST: second compilation of the forward kernels ("f16 products": one f16 MFMA product per fp32 product instead
+// of three; GELU / LayerNorm / accumulation stay fp32).  Its entry points carry the suffix _f16.  Every kernel and
+// device helper lives in an anonymous namespace so the two compilations of one source never share a symbol.
+#ifdef MPNN_FAST
+#define MPNN_API(name) name##_f16
+#else
+#define MPNN_API(name) name
+#endif
+
+namespace {
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -153,13 +164,17 @@ __device__ __forceinline__ void split_pair(const f32x4 a, const f32x4 b, BFrag& 
   for (int j = 0; j < 8; ++j) {
     const _Float16 h = (_Float16)v[j];
     o.hi[j] = h;
+#ifndef MPNN_FAST
     o.lo[j] = (_Float16)(v[j] - (float)h);
+#endif
   }
 }
 
 __device__ __forceinline__ f32x4 mfma_split(const h8 a_hi, const h8 a_lo, const BFrag& b, f32x4 acc) {
+#ifndef MPNN_FAST
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b.hi, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b.lo, acc, 0, 0, 0);
+#endif
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b.hi, acc, 0, 0, 0);
   return acc;
 }
@@ -171,6 +186,7 @@ __device__ __forceinline__ void split_kstep(WPtr Wp, int kk, int lane, const BFr
 #pragma unroll
   for (int to = TO0; to < TO1; ++to) {
     const h8 a_hi = Wp[((to * NKK + kk) * 2 + 0) * 64 + lane];
+#ifndef MPNN_FAST
     const h8 a_lo = Wp[((to * NKK + kk) * 2 + 1) * 64 + lane];
     // the three partial products of one accumulator are issued KT MFMAs apart (no back-to-back dependence)
 #pragma unroll
@@ -179,6 +195,7 @@ __device__ __forceinline__ void split_kstep(WPtr Wp, int kk, int lane, const BFr
 #pragma unroll
     for (int c = 0; c < KT; ++c)
       Y[to - TO0][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, B[c].lo, Y[to - TO0][c], 0, 0, 0);
+#endif
 #pragma unroll
     for (int c = 0; c < KT; ++c)
       Y[to - TO0][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, B[c].hi, Y[to - TO0][c], 0, 0, 0);
@@ -207,7 +224,9 @@ __device__ __forceinline__ void wring_load(WRing<D>& r, const h8* __restrict__ W
   // Wlane = packed base + lane; fragment (to, kk) lives at ((to * NKK + kk) * 2 + part) * 64
   const int to = q % NTO, kk = q / NTO;
   r.hi[q % (D + 1)] = Wlane[((to * NKK + kk) * 2 + 0) * 64];
+#ifndef MPNN_FAST
   r.lo[q % (D + 1)] = Wlane[((to * NKK + kk) * 2 + 1) * 64];
+#endif
 }
 
 template <int NKK, int NTO, int D>
@@ -225,11 +244,14 @@ __device__ __forceinline__ void split_kstep_stream(WRing<D>& r, const h8* __rest
   for (int to = 0; to < NTO; ++to) {
     const int q = kk * NTO + to;
     if (q + D < NKK * NTO) wring_load<NKK, NTO, D>(r, Wlane, q + D);
-    const h8 a_hi = r.hi[q % (D + 1)], a_lo = r.lo[q % (D + 1)];
+    const h8 a_hi = r.hi[q % (D + 1)];
+#ifndef MPNN_FAST
+    const h8 a_lo = r.lo[q % (D + 1)];
 #pragma unroll
     for (int c = 0; c < KT; ++c) Y[to][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, B[c].hi, Y[to][c], 0, 0, 0);
 #pragma unroll
     for (int c = 0; c < KT; ++c) Y[to][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, B[c].lo, Y[to][c], 0, 0, 0);
+#endif
 #pragma unroll
     for (int c = 0; c < KT; ++c) Y[to][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, B[c].hi, Y[to][c], 0, 0, 0);
   }
@@ -299,6 +321,8 @@ __device__ __forceinline__ void load_feature_row(const float* __restrict__ row, 
 #pragma unroll
   for (int t = 0; t < MPNN_NT; ++t) out[t] = *reinterpret_cast<const f32x4*>(row + 16 * t + 4 * g);
 }
+
+}  // namespace
 
 // host-side error plumbing shared by the launchers
 extern "C" void mpnn_set_error(const char* msg);

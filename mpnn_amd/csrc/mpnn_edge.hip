@@ -22,6 +22,8 @@
 // Two waves per SIMD (8-wave workgroups) let one wave's GELU / reductions run under the other's MFMAs.
 #include "mpnn_edge_common.h"
 
+namespace {
+
 #ifndef MPNN_MSG_WAVES
 #define MPNN_MSG_WAVES 8
 #endif
@@ -473,10 +475,12 @@ k_message_tiles(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, in
   }
 }
 
+}  // namespace
+
 // ===========================================================================
 // C ABI launchers
 // ===========================================================================
-extern "C" int mpnn_enc_message(const float* hE_frag, const float* PQ, int ldpq, int offP, int offQ,
+extern "C" int MPNN_API(mpnn_enc_message)(const float* hE_frag, const float* PQ, int ldpq, int offP, int offQ,
                                 const int32_t* E_idx32, const float* mask, const float* edge_mask,
                                 const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K,
                                 float* gsum, float* cnt, void* stream) {
@@ -500,7 +504,7 @@ extern "C" int mpnn_enc_message(const float* hE_frag, const float* PQ, int ldpq,
   MPNN_LAUNCH_CHECK();
 }
 
-extern "C" int mpnn_enc_edge_update(float* hE_frag, const float* PQ, int ldpq, int offP, int offQ,
+extern "C" int MPNN_API(mpnn_enc_edge_update)(float* hE_frag, const float* PQ, int ldpq, int offP, int offQ,
                                     const int32_t* E_idx32, const float* W11b_packed, const float* W12_packed,
                                     const float* b12, const float* W13_packed, const float* b13, const float* ln_w,
                                     const float* ln_b, int B, int L, int K, void* stream) {
@@ -517,7 +521,7 @@ extern "C" int mpnn_enc_edge_update(float* hE_frag, const float* PQ, int ldpq, i
   MPNN_LAUNCH_CHECK();
 }
 
-extern "C" int mpnn_dec_message(const float* hE_frag, const float* PQ, int ldpq, int offPa, int offA,
+extern "C" int MPNN_API(mpnn_dec_message)(const float* hE_frag, const float* PQ, int ldpq, int offPa, int offA,
                                 const float* PVenc, int ldenc, int offEnc, const int32_t* rank,
                                 const int32_t* E_idx32, const float* mask, const float* edge_mask,
                                 const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K,
@@ -543,6 +547,7 @@ extern "C" int mpnn_dec_message(const float* hE_frag, const float* PQ, int ldpq,
 }
 
 // ---- training forward: same kernels, pre-activations saved for mpnn_edge_bwd.hip (K <= 48) ----
+#ifndef MPNN_FAST
 extern "C" int mpnn_message_train(int dec, const float* hE_frag, const float* P, const float* RowA, const float* RowB,
                                   const int32_t* rank, const int32_t* E_idx32, const float* mask,
                                   const float* edge_mask, const float* W1b_packed, const float* W2_packed,
@@ -568,7 +573,9 @@ extern "C" int mpnn_message_train(int dec, const float* hE_frag, const float* P,
   }
   MPNN_LAUNCH_CHECK();
 }
+#endif
 
+#ifndef MPNN_FAST
 extern "C" int mpnn_enc_edge_update_train(const float* hE_frag, const float* P, const float* Q, const int32_t* E_idx32,
                                           const float* W11b_packed, const float* W12_packed, const float* b12,
                                           const float* W13_packed, const float* b13, const float* ln_w,
@@ -591,9 +598,10 @@ extern "C" int mpnn_enc_edge_update_train(const float* hE_frag, const float* P, 
                                      (unsigned)drop_seed, 1.0f / (1.0f - p_drop)));
   MPNN_LAUNCH_CHECK();
 }
+#endif
 
 // ---- autoregressive sampling: decoder message for a listed subset of residues of samples sharing one encoder ----
-extern "C" int mpnn_dec_message_subset(const float* hE_frag, const float* P, int ldp, int offP, const float* RowA,
+extern "C" int MPNN_API(mpnn_dec_message_subset)(const float* hE_frag, const float* P, int ldp, int offP, const float* RowA,
                                        int lda, int offA, const float* PVenc, int ldenc, int offEnc,
                                        const int32_t* rank, const int32_t* E_idx32, const float* mask,
                                        const float* edge_mask, const float* W1b_packed, const float* W2_packed,

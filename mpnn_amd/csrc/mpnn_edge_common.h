@@ -2,6 +2,7 @@
 #pragma once
 #include "mpnn_common.h"
 
+namespace {
 // make a (uniform) pointer opaque once per loop iteration: keeps LICM from hoisting hundreds of
 // loop-invariant weight / bias loads out of the persistent loop and pinning them in registers
 #define LAUNDER(p) asm volatile("" : "+s"(p))
@@ -39,6 +40,8 @@ __device__ __forceinline__ f32x4 dropout4(f32x4 v, unsigned id0, unsigned seed, 
 
 constexpr int NKK = MPNN_NT / 2;       // k-steps (32 features) per 128-wide layer
 constexpr int WSPLIT = 8 * NKK * 2 * 64;  // h8 elements of one packed 128x128 matrix (64 KiB)
+
+}  // namespace
 
 // ---- host side -------------------------------------------------------------
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -3,6 +3,8 @@
 // round every operation exactly like the reference's separate ATen ops do.
 #include "mpnn_common.h"
 
+namespace {
+
 // ---------------------------------------------------------------------------
 // backbone atoms: X [N,4,3] (+noise) -> atoms [N][6][4] = N, CA, C, O, CB, V (xyz + pad)
 //                                        ca_soa [B][4][L] = CA.x, CA.y, CA.z, mask
@@ -459,11 +461,14 @@ __global__ void k_order_masks(const int* __restrict__ rank, const long long* __r
   mask_fw[idx] = fw;
 }
 
+}  // namespace
+
 // ===========================================================================
 // C ABI launchers (declared in include/mpnn_hip.h)
 // ===========================================================================
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+#ifndef MPNN_FAST
 extern "C" int mpnn_backbone_atoms(const float* X, const float* noise, const float* mask, int B, int L,
                                    float* atoms, float* ca_soa, void* stream) {
   MPNN_CHECK_ARG(X && mask && atoms && ca_soa && B > 0 && L > 0, "mpnn_backbone_atoms: bad arguments");
@@ -472,7 +477,9 @@ extern "C" int mpnn_backbone_atoms(const float* X, const float* noise, const flo
                      L, atoms, ca_soa);
   MPNN_LAUNCH_CHECK();
 }
+#endif
 
+#ifndef MPNN_FAST
 extern "C" int mpnn_knn_topk(const float* ca_soa, int B, int L, int K, float edge_cutoff, int64_t* E_idx64,
                              int32_t* E_idx32, float* D_neighbors, float* edge_mask, void* stream) {
   MPNN_CHECK_ARG(ca_soa && E_idx32 && B > 0 && L > 0, "mpnn_knn_topk: bad arguments");
@@ -484,7 +491,9 @@ extern "C" int mpnn_knn_topk(const float* ca_soa, int B, int L, int K, float edg
                      K, Kp, has_cut, edge_cutoff, (long long*)E_idx64, E_idx32, D_neighbors, edge_mask);
   MPNN_LAUNCH_CHECK();
 }
+#endif
 
+#ifndef MPNN_FAST
 extern "C" int mpnn_occupancy(const float* atoms, const float* mask, int B, int L, float cutoff, float* occ,
                               void* stream) {
   MPNN_CHECK_ARG(atoms && mask && occ && B > 0 && L > 0 && cutoff > 0.f, "mpnn_occupancy: bad arguments");
@@ -492,7 +501,9 @@ extern "C" int mpnn_occupancy(const float* atoms, const float* mask, int B, int 
                      B, L, cutoff, occ);
   MPNN_LAUNCH_CHECK();
 }
+#endif
 
+#ifndef MPNN_FAST
 extern "C" int mpnn_pack_linear(const float* W, int out_f, int in_f, int ld, int col0, float* packed, void* stream) {
   MPNN_CHECK_ARG(W && packed && out_f > 0 && in_f > 0 && ld >= col0 + in_f, "mpnn_pack_linear: bad arguments");
   const int nto = (out_f + 15) / 16, nti = (in_f + 15) / 16;
@@ -500,7 +511,9 @@ extern "C" int mpnn_pack_linear(const float* W, int out_f, int in_f, int ld, int
                      W, out_f, in_f, ld, col0, packed, nto, nti);
   MPNN_LAUNCH_CHECK();
 }
+#endif
 
+#ifndef MPNN_FAST
 extern "C" int mpnn_pack_linear_split(const float* W, int out_f, int in_f, int ld, int col0, int rot, void* packed,
                                       void* stream) {
   MPNN_CHECK_ARG(W && packed && out_f > 0 && in_f > 0 && ld >= col0 + in_f && rot >= 0 && rot < in_f,
@@ -510,13 +523,16 @@ extern "C" int mpnn_pack_linear_split(const float* W, int out_f, int in_f, int l
                      (hipStream_t)stream, W, out_f, in_f, ld, col0, rot, (h8*)packed, nto, nkk);
   MPNN_LAUNCH_CHECK();
 }
+#endif
 
+#ifndef MPNN_FAST
 extern "C" int mpnn_pos_table(const float* W, const float* bias, int nbuckets, int npos, float* table, void* stream) {
   MPNN_CHECK_ARG(W && bias && table && nbuckets == 66 && npos == 16, "mpnn_pos_table: expects a 16x66 linear");
   hipLaunchKernelGGL(k_pos_table, dim3(ceil_div(nbuckets * npos, 256)), dim3(256), 0, (hipStream_t)stream, W, bias,
                      nbuckets, npos, table);
   MPNN_LAUNCH_CHECK();
 }
+#endif
 
 template <int KT>
 static int launch_edge_features(int A, const float* atoms, const int* E_idx, const long long* ridx,
@@ -539,7 +555,7 @@ static int launch_edge_features(int A, const float* atoms, const int* E_idx, con
   MPNN_LAUNCH_CHECK();
 }
 
-extern "C" int mpnn_edge_features(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
+extern "C" int MPNN_API(mpnn_edge_features)(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
                                   const int64_t* chain_labels, const float* pos_table, const float* rbf_mu,
                                   const float* Wemb_packed, const float* ln_w, const float* ln_b,
                                   const float* We_packed, const float* We_bias, int B, int L, int K, int n_atoms,
@@ -560,6 +576,7 @@ extern "C" int mpnn_edge_features(const float* atoms, const int32_t* E_idx32, co
   }
 }
 
+#ifndef MPNN_FAST
 extern "C" int mpnn_edge_features_train(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
                                         const int64_t* chain_labels, const float* pos_table, const float* rbf_mu,
                                         const float* Wemb_packed, const float* ln_w, const float* ln_b,
@@ -579,7 +596,10 @@ extern "C" int mpnn_edge_features_train(const float* atoms, const int32_t* E_idx
     default: return launch_edge_features<3>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag);
   }
 }
+#endif
 
+#ifndef MPNN_FAST
+namespace {
 // ---------------------------------------------------------------------------
 // Training: the featurizer's raw inputs, materialised once per backward pass in the fragment layout so that the
 // generic per-edge weight-gradient kernel (mpnn_edge_wgrad) can contract them with dE0:
@@ -633,6 +653,9 @@ k_feature_chunks(const float* __restrict__ atoms, const int* __restrict__ E_idx,
   }
 }
 
+}  // namespace
+#endif
+#ifndef MPNN_FAST
 extern "C" int mpnn_feature_chunks(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
                                    const int64_t* chain_labels, const float* rbf_mu, int B, int L, int K, int n_atoms,
                                    float* chunks_frag, void* stream) {
@@ -650,7 +673,9 @@ extern "C" int mpnn_feature_chunks(const float* atoms, const int32_t* E_idx32, c
                        (f32x4*)chunks_frag);
   MPNN_LAUNCH_CHECK();
 }
+#endif
 
+#ifndef MPNN_FAST
 extern "C" int mpnn_edges_to_natural(const float* hE_frag, int n_nodes, int K, float* natural, void* stream) {
   MPNN_CHECK_ARG(hE_frag && natural && n_nodes > 0 && K >= 1 && K <= 64, "mpnn_edges_to_natural: bad arguments");
   const int KT = (K + 15) / 16;
@@ -659,7 +684,9 @@ extern "C" int mpnn_edges_to_natural(const float* hE_frag, int n_nodes, int K, f
                      n_nodes, K, KT, natural);
   MPNN_LAUNCH_CHECK();
 }
+#endif
 
+#ifndef MPNN_FAST
 extern "C" int mpnn_edges_from_natural(const float* natural, int n_nodes, int K, float* hE_frag, void* stream) {
   MPNN_CHECK_ARG(hE_frag && natural && n_nodes > 0 && K >= 1 && K <= 64, "mpnn_edges_from_natural: bad arguments");
   const int KT = (K + 15) / 16;
@@ -668,14 +695,18 @@ extern "C" int mpnn_edges_from_natural(const float* natural, int n_nodes, int K,
                      n_nodes, K, KT, hE_frag);
   MPNN_LAUNCH_CHECK();
 }
+#endif
 
+#ifndef MPNN_FAST
 extern "C" int mpnn_order_rank(const int64_t* order, int B, int L, int32_t* rank, void* stream) {
   MPNN_CHECK_ARG(order && rank && B > 0 && L > 0, "mpnn_order_rank: bad arguments");
   hipLaunchKernelGGL(k_order_rank, dim3(ceil_div((long long)B * L, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const long long*)order, B, L, rank);
   MPNN_LAUNCH_CHECK();
 }
+#endif
 
+#ifndef MPNN_FAST
 extern "C" int mpnn_order_masks(const int32_t* rank, const int64_t* E_idx64, const float* mask,
                                 const float* edge_mask, int B, int L, int K, float* mask_bw, float* mask_fw,
                                 void* stream) {
@@ -685,3 +716,4 @@ extern "C" int mpnn_order_masks(const int32_t* rank, const int64_t* E_idx64, con
                      (const long long*)E_idx64, mask, edge_mask, B, L, K, mask_bw, mask_fw);
   MPNN_LAUNCH_CHECK();
 }
+#endif

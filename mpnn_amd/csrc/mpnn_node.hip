@@ -3,6 +3,8 @@
 // (reference: src/mpnn/models/model_utils.py :81-88, :127-137, :151-155, :414-421, :527-528).
 #include "mpnn_common.h"
 
+namespace {
+
 // ---------------------------------------------------------------------------
 // node update + projections: one wavefront per 16 nodes, 4 waves (64 nodes) per workgroup, split-f16 MFMA.
 //   dh  = (W3 gsum + cnt b3) / scale                               (:78-81 with W3 hoisted)
@@ -217,12 +219,14 @@ k_logits(const float* __restrict__ hV, const f32x4* __restrict__ Wp, const float
   }
 }
 
+}  // namespace
+
 // ===========================================================================
 // C ABI launchers
 // ===========================================================================
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-extern "C" int mpnn_node_update(const float* hV_in, const float* gsum, const float* cnt, float cnt_const,
+extern "C" int MPNN_API(mpnn_node_update)(const float* hV_in, const float* gsum, const float* cnt, float cnt_const,
                                 const float* mask, const float* W3_packed, const float* b3, const float* ln1_w,
                                 const float* ln1_b, const float* Win_packed, const float* b_in,
                                 const float* Wout_packed, const float* b_out, const float* ln2_w, const float* ln2_b,
@@ -246,7 +250,7 @@ extern "C" int mpnn_node_update(const float* hV_in, const float* gsum, const flo
   MPNN_LAUNCH_CHECK();
 }
 
-extern "C" int mpnn_node_update_subset(const float* hV_in, const float* gsum, float cnt_const, const float* mask,
+extern "C" int MPNN_API(mpnn_node_update_subset)(const float* hV_in, const float* gsum, float cnt_const, const float* mask,
                                        const float* W3_packed, const float* b3, const float* ln1_w,
                                        const float* ln1_b, const float* Win_packed, const float* b_in,
                                        const float* Wout_packed, const float* b_out, const float* ln2_w,
@@ -265,6 +269,8 @@ extern "C" int mpnn_node_update_subset(const float* hV_in, const float* gsum, fl
   MPNN_LAUNCH_CHECK();
 }
 
+#ifndef MPNN_FAST
+namespace {
 // ---------------------------------------------------------------------------
 // Sampling head for a listed subset of residues (one wave = 16 residues):
 //   logits = W_out h + b;  log_probs = log_softmax(logits)  (the model's distribution, what a teacher-forced
@@ -389,6 +395,9 @@ k_sample(const float* __restrict__ hV, const f32x4* __restrict__ Wp, const float
   }
 }
 
+}  // namespace
+#endif
+#ifndef MPNN_FAST
 extern "C" int mpnn_sample_subset(const float* hV, const float* Wout_packed, const float* bias, const float* logit_bias,
                                   int n_letters, const int32_t* node_list, int n_list, float temperature,
                                   uint64_t seed, const float* designable, const int64_t* S_in, int64_t* S_out,
@@ -412,7 +421,9 @@ extern "C" int mpnn_sample_subset(const float* hV, const float* Wout_packed, con
                      ld_ts, rows);
   MPNN_LAUNCH_CHECK();
 }
+#endif
 
+#ifndef MPNN_FAST
 extern "C" int mpnn_occupancy_mlp(const float* occ, const float* w0, const float* b0, const float* W2_packed,
                                   const float* b2, const float* ln_w, const float* ln_b, int n_nodes, float* hV,
                                   void* stream) {
@@ -422,7 +433,9 @@ extern "C" int mpnn_occupancy_mlp(const float* occ, const float* w0, const float
                      (const f32x4*)W2_packed, b2, ln_w, ln_b, n_nodes, hV);
   MPNN_LAUNCH_CHECK();
 }
+#endif
 
+#ifndef MPNN_FAST
 extern "C" int mpnn_logits_log_softmax(const float* hV, const float* Wout_packed, const float* bias, int n_letters,
                                        int n_nodes, float* log_probs, void* stream) {
   MPNN_CHECK_ARG(hV && Wout_packed && bias && log_probs && n_nodes > 0 && n_letters >= 1 && n_letters <= 32,
@@ -431,3 +444,4 @@ extern "C" int mpnn_logits_log_softmax(const float* hV, const float* Wout_packed
                      (const f32x4*)Wout_packed, bias, n_letters, n_nodes, log_probs);
   MPNN_LAUNCH_CHECK();
 }
+#endif

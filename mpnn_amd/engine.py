@@ -171,7 +171,12 @@ class PackedWeights:
 def packed(model) -> PackedWeights:
     pw = getattr(model, "_packed", None)
     if pw is None or pw.key != PackedWeights.make_key(model):
-        pw = PackedWeights(model)
+        saved = _lib._suffix  # derived tables (TS) are always built with fp32-class products
+        _lib._suffix = ""
+        try:
+            pw = PackedWeights(model)
+        finally:
+            _lib._suffix = saved
         model._packed = pw
     return pw
 
@@ -298,6 +303,16 @@ def forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_ord
     """ProteinMPNN.forward (reference :427-529) on the HIP kernels, inference form (no autograd graph; the
     differentiable form is training.forward_train, which ProteinMPNN.forward picks in training mode)."""
     _require_device(X, "X")
+    _lib.set_precision(getattr(model, "precision", "fp32"))
+    try:
+        return _forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order, fix_backbone_noise,
+                        return_intermediates)
+    finally:
+        _lib.set_precision("fp32")
+
+
+def _forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order, fix_backbone_noise,
+             return_intermediates):
     dev = X.device
     mask = _f32(mask)
     B, L = mask.shape
@@ -474,6 +489,16 @@ def sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true=None
     teacher-forced forward on S with the same order returns them), order [n_samples,B,L]).  Residues with
     chain_M * mask == 0 are not designed: they keep S_true.  The featurizer and encoder run once per structure."""
     _require_device(X, "X")
+    _lib.set_precision(getattr(model, "precision", "fp32"))
+    try:
+        return _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_samples, temperature, seed,
+                       fix_order, logit_bias, backbone_noise)
+    finally:
+        _lib.set_precision("fp32")
+
+
+def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_samples, temperature, seed, fix_order,
+            logit_bias, backbone_noise):
     dev = X.device
     mask = _f32(mask)
     B, L = mask.shape
@@ -520,23 +545,44 @@ def sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true=None
         A_ld = (ctypes.c_int * n_dec)(*([2 * H] * n_dec))
         A_off = (ctypes.c_int * n_dec)(*([H] * n_dec))
         lb = _f32(logit_bias).to(dev) if logit_bias is not None else None
+        # ~7 launches per level and ~75 levels: argument lists are built once, only (list pointer, count) change
+        lib = _lib.load()
+        plans = []
+        for l, lw in enumerate(pw.dec):
+            grp = pw.g_dec[l]
+            msg = [ptr(enc["hE"]), ptr(PA[l]), 2 * H, 0, ptr(PA[l]), 2 * H, H, ptr(PQenc), PQenc.shape[1],
+                   base + 2 * H + H * l, ptr(rank), ptr(enc["E_idx32"]), ptr(mask_s), ptr(enc["edge_mask"]),
+                   ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"]), None, 0, N, L, K, ptr(gsum), st]
+            node = [ptr(hVs[l]), ptr(gsum), float(K), ptr(mask_s), ptr(lw["W3"]), ptr(lw["b3"]), ptr(lw["ln1w"]),
+                    ptr(lw["ln1b"]), ptr(lw["Win"]), ptr(lw["bin"]), ptr(lw["Wout"]), ptr(lw["bout"]), ptr(lw["ln2w"]),
+                    ptr(lw["ln2b"]), lw["scale"], ptr(grp[0]), ptr(grp[1]), grp[2], None, 0, ptr(hVs[l + 1]),
+                    ptr(PA[l + 1]) if grp[2] else None, st]
+            plans.append((msg, node))
+        head = [ptr(hVs[n_dec]), ptr(pw.Wlogit), ptr(pw.blogit), ptr(lb), pw.n_letters, None, 0, float(temperature),
+                int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(designable), ptr(S_in), ptr(S_out), ptr(log_probs), ptr(pw.TS),
+                pw.TS.shape[1], n_dec, A_rows, A_ld, A_off, st]
+        f_msg = getattr(lib, _lib.entry("mpnn_dec_message_subset"))
+        f_node = getattr(lib, _lib.entry("mpnn_node_update_subset"))
+        f_head = lib.mpnn_sample_subset
+        if _lib._profile is not None:  # bench.py's per-entry-point timing goes through the generic wrapper
+            f_msg = lambda *a: (call("mpnn_dec_message_subset", *a), 0)[1]
+            f_node = lambda *a: (call("mpnn_node_update_subset", *a), 0)[1]
+            f_head = lambda *a: (call("mpnn_sample_subset", *a), 0)[1]
+        list_ptr = perm.data_ptr()
         start = 0
+        rc = 0
         for cnt_l in counts:
-            nodes = perm[start:start + cnt_l]
+            p_nodes = list_ptr + 4 * start
             start += cnt_l
-            for l, lw in enumerate(pw.dec):
-                call("mpnn_dec_message_subset", ptr(enc["hE"]), ptr(PA[l]), 2 * H, 0, ptr(PA[l]), 2 * H, H, ptr(PQenc),
-                     PQenc.shape[1], base + 2 * H + H * l, ptr(rank), ptr(enc["E_idx32"]), ptr(mask_s),
-                     ptr(enc["edge_mask"]), ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"]), nodes.data_ptr(), cnt_l, N, L,
-                     K, ptr(gsum), st)
-                grp = pw.g_dec[l]
-                call("mpnn_node_update_subset", ptr(hVs[l]), ptr(gsum), float(K), ptr(mask_s), ptr(lw["W3"]),
-                     ptr(lw["b3"]), ptr(lw["ln1w"]), ptr(lw["ln1b"]), ptr(lw["Win"]), ptr(lw["bin"]), ptr(lw["Wout"]),
-                     ptr(lw["bout"]), ptr(lw["ln2w"]), ptr(lw["ln2b"]), lw["scale"], ptr(grp[0]), ptr(grp[1]), grp[2],
-                     nodes.data_ptr(), cnt_l, ptr(hVs[l + 1]), ptr(PA[l + 1]) if grp[2] else None, st)
-            call("mpnn_sample_subset", ptr(hVs[n_dec]), ptr(pw.Wlogit), ptr(pw.blogit), ptr(lb), pw.n_letters,
-                 nodes.data_ptr(), cnt_l, float(temperature), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(designable),
-                 ptr(S_in), ptr(S_out), ptr(log_probs), ptr(pw.TS), pw.TS.shape[1], n_dec, A_rows, A_ld, A_off, st)
+            for msg, node in plans:
+                msg[17], msg[18] = p_nodes, cnt_l
+                node[18], node[19] = p_nodes, cnt_l
+                rc = rc or f_msg(*msg) or f_node(*node)
+            head[5], head[6] = p_nodes, cnt_l
+            rc = rc or f_head(*head)
+        if rc:
+            raise RuntimeError(f"mpnn_amd.sample: kernel launch failed (code {rc}): "
+                               f"{lib.mpnn_last_error().decode(errors='replace')}")
     return dict(S=S_out.view(n_samples, B, L), log_probs=log_probs.view(n_samples, B, L, -1),
                 order=order.view(n_samples, B, L), n_levels=len(counts))
 

@@ -153,6 +153,16 @@ class ProteinMPNN(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
         self._packed = None  # engine.PackedWeights cache
+        self.precision = "fp32"  # forward arithmetic: "fp32" (default) or "f16" (see set_precision)
+
+    def set_precision(self, mode):
+        """'fp32': every product fp32-class (three f16 MFMA products, fp32 accumulate).  'f16': one f16 product per
+        fp32 product in inference forward / sampling (bf16-class accuracy, stated in include/mpnn_hip.h); training
+        always runs fp32-class."""
+        if mode not in ("fp32", "f16"):
+            raise ValueError("precision must be 'fp32' or 'f16'")
+        self.precision = mode
+        return self
 
     def forward(self, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order=None,
                 fix_backbone_noise=None):

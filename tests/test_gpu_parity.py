@@ -245,3 +245,28 @@ def test_large_complex_L4096_vs_oracle():
     same(out["D_neighbors"].cpu().numpy(), ref["D_neighbors"].numpy(), "D_neighbors")
     same(out["mask_bw"].cpu().numpy(), ref["mask_bw"].numpy(), "mask_bw")
     assert_close(out["log_probs"].cpu().numpy(), ref["log_probs"].numpy(), LP_RTOL, LP_ATOL, "log_probs")
+
+
+@pytest.mark.parametrize("shape", [dict(B=4, L=512, seed=31), dict(B=1, L=4096, seed=32, n_chains=4)])
+def test_f16_product_mode_tolerance(shape):
+    """Reduced-precision forward (one f16 product per fp32 product; BASELINE configs[3] "bf16 message MLPs"):
+    neighbour lists identical to the fp32 path, max |d log_prob| <= 5e-2 and argmax agreement >= 99 % against the
+    fp32-class path (itself pinned to the oracle above)."""
+    from mpnn_amd.synthetic import synthetic_batch
+
+    model = build_model(dict(k_neighbors=48))
+    b = synthetic_batch(design_fraction=0.7, **shape)
+    rec = {n: v.numpy() for n, v in b.items()}
+    ref = run_hip(model, rec)
+    model.set_precision("f16")
+    out = run_hip(model, rec)
+    model.set_precision("fp32")
+    again = run_hip(model, rec, keep=False)
+    same(out["E_idx"].cpu().numpy(), ref["E_idx"].cpu().numpy(), "E_idx")
+    same(out["mask_bw"].cpu().numpy(), ref["mask_bw"].cpu().numpy(), "mask_bw")
+    same(again.cpu().numpy(), ref["log_probs"].cpu().numpy(), "fp32 mode restored bit-for-bit")
+    d = (out["log_probs"] - ref["log_probs"]).abs()
+    agree = (out["log_probs"].argmax(-1) == ref["log_probs"].argmax(-1)).float().mean().item()
+    print(f"f16 products: max |d log_prob| {d.max().item():.2e}, mean {d.mean().item():.2e}, argmax agreement {agree:.4f}")
+    assert d.max().item() <= 5e-2
+    assert agree >= 0.99
