@@ -12,6 +12,7 @@ whole-job residues/s, the roofline of the dominant kernel (HIP-event timed on it
 the CPU baseline (the oracle's reference formulation on a bounded sample, rank 0, N=1 only).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -43,31 +44,62 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # for reference: the f32-input MFMA / f32 vector 
 
 
 def cpu_baseline(B_cpu, L, K, iters):
-    """The oracle in the reference's formulation (same [B,L,L] temporaries and O(L^3) mask einsum),
-    timed on this host's cores."""
+    """The oracle in the reference's formulation (same [B,L,L] temporaries and O(L^3) mask einsum), timed on this
+    host's cores: forward at all (<= 16) threads (the headline `value`), forward on one thread, and one training step
+    (forward + autograd backward; the optimizer is negligible) at all threads.  Bounded samples, ~20 s in total."""
     from mpnn_amd import ProteinMPNN
     from mpnn_amd.synthetic import synthetic_batch
     from oracle import mpnn_oracle as orc
 
     threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
     model = ProteinMPNN(k_neighbors=K, augment_eps=0.0, dropout=0.0).eval()
     sd = {k: v.detach() for k, v in model.state_dict().items()}
     cfg = orc.Config(k_neighbors=K)
-    b = synthetic_batch(B_cpu, L, seed=123)
-    args = (b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
-    times = []
-    with torch.no_grad():
-        orc.forward(sd, cfg, *args, fix_order=b["fix_order"], formulation="reference")  # warm-up
-        for _ in range(iters):
+
+    def fwd_time(nthreads, Bc, n):
+        torch.set_num_threads(nthreads)
+        b = synthetic_batch(Bc, L, seed=123)
+        args = (b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
+        times = []
+        with torch.no_grad():
+            orc.forward(sd, cfg, *args, fix_order=b["fix_order"], formulation="reference")  # warm-up
+            for _ in range(n):
+                t0 = time.perf_counter()
+                orc.forward(sd, cfg, *args, fix_order=b["fix_order"], formulation="reference")
+                times.append(time.perf_counter() - t0)
+        times.sort()
+        return times[len(times) // 2]
+
+    def train_time(nthreads, Bc, n):
+        torch.set_num_threads(nthreads)
+        b = synthetic_batch(Bc, L, seed=124)
+        args = (b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        times = []
+        for i in range(n + 1):
             t0 = time.perf_counter()
-            orc.forward(sd, cfg, *args, fix_order=b["fix_order"], formulation="reference")
-            times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
+            lp = orc.forward(sdg, cfg, *args, fix_order=b["fix_order"], formulation="reference")
+            _, loss = orc.loss_smoothed(b["S"], lp, b["mask"] * b["chain_M"])
+            loss.backward()
+            if i:
+                times.append(time.perf_counter() - t0)
+            for v in sdg.values():
+                v.grad = None
+        times.sort()
+        return times[len(times) // 2]
+
+    med = fwd_time(threads, B_cpu, iters)
+    one = fwd_time(1, 1, 2)
+    trn = train_time(threads, 1, 2)
+    torch.set_num_threads(threads)
     return {"value": B_cpu * L / med, "unit": "residues/s", "cores": threads, "kind": "port",
             "sample": f"oracle (reference formulation, fp32, torch CPU) forward on B={B_cpu} x L={L}, k={K}: "
-                      f"median of {iters} runs after 1 warm-up, {med * 1e3:.0f} ms each"}
+                      f"median of {iters} runs after 1 warm-up, {med * 1e3:.0f} ms each",
+            "forward_single_thread": {"value": round(L / one, 1), "cores": 1,
+                                      "sample": f"same, B=1 x L={L}, median of 2, {one * 1e3:.0f} ms each"},
+            "train_step": {"value": round(L / trn, 1), "cores": threads,
+                           "sample": f"forward + loss_smoothed + autograd backward, B=1 x L={L}, median of 2, "
+                                     f"{trn * 1e3:.0f} ms each"}}
 
 
 def train_leg(a, dev, rank, world, dist, barrier, _lib):
@@ -77,11 +109,16 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
     from mpnn_amd.synthetic import synthetic_batch
 
     B, L, K = a.train_batch, a.length, a.k
+    # objects of the earlier legs (models, thousands of timing events) would be re-scanned by every cyclic-GC pass the
+    # autograd graph triggers (measured: 24 instead of 17 ms per step): collect once, then exclude them from scanning
+    gc.collect()
+    gc.freeze()
     torch.manual_seed(1234)
     model = ProteinMPNN(k_neighbors=K, augment_eps=0.0, dropout=0.0).train().to(dev)
     if world > 1:
         distributed.broadcast_parameters(model.parameters())
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2)
+    # AdamW(lr, weight_decay=1e-2) as train.py:217; the fused multi-tensor implementation is the same update in one launch
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2, fused=True)
     b = synthetic_batch(B, L, seed=2000 + rank, device=dev)
     batch = (b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
     steps, warm = max(3, min(a.steps, 10)), 2
@@ -95,6 +132,7 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
     t0 = time.perf_counter()
     for _ in range(steps):
         loss, _ = step()
+    enqueue = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -112,7 +150,8 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
     hip_ms = sum(kern.values())
     return {"metric": "residues/sec (train step: fwd + bwd + AdamW) at L=512,k=48",
             "value": round(B * L * world * steps / elapsed, 1), "unit": "residues/s", "n_gpus": world, "steps": steps,
-            "warmup": warm, "ms_per_step": round(elapsed / steps * 1e3, 3), "scaling": "weak",
+            "warmup": warm, "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "host_enqueue_ms_per_step": round(enqueue / steps * 1e3, 3), "scaling": "weak",
             "config": {"workload": f"BASELINE configs[2]: {B} x L={L} = {B * L} residues per rank, k={K}, dropout 0, "
                                    "AdamW, one flat gradient all-reduce per step", "global_batch": B * world},
             "final_loss": round(float(loss), 6),
@@ -171,6 +210,7 @@ def main():
     ap.add_argument("--length", type=int, default=512)
     ap.add_argument("--k", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f16-leg", action="store_true", help="skip the reduced-precision forward leg")
     ap.add_argument("--train-batch", type=int, default=20,
                     help="proteins per rank in the training leg (BASELINE configs[2]: ~10k-residue batches); 0 = skip")
     ap.add_argument("--samples", type=int, default=64,
@@ -272,7 +312,7 @@ def main():
 
     # ---- secondary: reduced-precision forward (one f16 product per fp32 product), same workload and the L=4096 shape
     f16 = {}
-    for tag, (Bq, Lq) in {"B%dxL%d" % (B, L): (B, L), "B4xL4096": (4, 4096)}.items():
+    for tag, (Bq, Lq) in ({} if a.no_f16_leg else {"B%dxL%d" % (B, L): (B, L), "B4xL4096": (4, 4096)}).items():
         bq = b if (Bq, Lq) == (B, L) else synthetic_batch(Bq, Lq, seed=4000 + rank, device=dev)
         aq = (bq["X"], bq["S"], bq["mask"], bq["chain_M"], bq["residue_idx"], bq["chain_encoding_all"])
         res = {}
