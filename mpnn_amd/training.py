@@ -46,7 +46,8 @@ class Graph:
         self.src = src.expand(-1, K).reshape(-1)
         self.perm = torch.argsort(self.dest, stable=True)
         self.inv_row = rows[self.perm].to(torch.int32).contiguous()
-        counts = torch.bincount(self.dest, minlength=self.N)
+        # (torch.bincount synchronises with the host to size its output; scatter_add does not)
+        counts = torch.zeros(self.N, device=dev, dtype=torch.int64).scatter_add_(0, self.dest, torch.ones_like(self.dest))
         self.inv_ptr = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]).to(torch.int32).contiguous()
         self.rank = None
         self.sel = None
