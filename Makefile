@@ -16,7 +16,7 @@ $(CSRC)/mpnn_featurizer.o: $(CSRC)/mpnn_featurizer.hip $(CSRC)/mpnn_common.h
 $(CSRC)/mpnn_edge.o: $(CSRC)/mpnn_edge.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/mpnn_edge_bwd.o: $(CSRC)/mpnn_edge_bwd.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h
+$(CSRC)/mpnn_edge_bwd.o: $(CSRC)/mpnn_edge_bwd.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h $(CSRC)/mpnn_bwd_common.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/mpnn_abi.o: $(CSRC)/mpnn_abi.cpp
@@ -33,7 +33,7 @@ clean:
 $(CSRC)/mpnn_node.o: $(CSRC)/mpnn_node.hip $(CSRC)/mpnn_common.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/mpnn_node_bwd.o: $(CSRC)/mpnn_node_bwd.hip $(CSRC)/mpnn_common.h
+$(CSRC)/mpnn_node_bwd.o: $(CSRC)/mpnn_node_bwd.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h $(CSRC)/mpnn_bwd_common.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 # second compilation of the forward kernels with one f16 product per fp32 product (entry points *_f16)

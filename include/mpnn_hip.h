@@ -202,6 +202,29 @@ int mpnn_feature_chunks(const float* atoms, const int32_t* E_idx32, const int64_
                         const int64_t* chain_labels, const float* rbf_mu, int B, int L, int K, int n_atoms,
                         float* chunks_frag, void* stream);
 
+/* Training forward of mpnn_node_update (:81-88, :127-137, :151-155): also stores x1pre = h + drop(dh), the FFN
+ * pre-activation a [n_nodes,512] and x2pre = x1 + drop(FFN) for the backward kernel; applies the layers' two node-level
+ * dropouts (counter-based, ids node*128+feature; the second with seed ^ 0x5bd1e995) when p_drop > 0; writes the
+ * projections block-major PQ_blocks[p][node][128].  No table add (the sequence term is added by the caller). */
+int mpnn_node_update_train(const float* hV_in, const float* gsum, const float* cnt, float cnt_const, const float* mask,
+                           const float* W3_packed, const float* b3, const float* ln1_w, const float* ln1_b,
+                           const float* Win_packed, const float* b_in, const float* Wout_packed, const float* b_out,
+                           const float* ln2_w, const float* ln2_b, float scale, const float* Wproj_packed,
+                           const float* bproj, int nproj, int n_nodes, float* hV_out, float* PQ_blocks, float* x1pre,
+                           float* a_pre, float* x2pre, float p_drop, uint32_t drop_seed, void* stream);
+
+/* Backward of the node update.  Inputs: dY = d hV_out (may be NULL), dPQ_blocks[p][node][128], the saved tensors.
+ * *T_packed = mpnn_pack_linear_split of the transposed matrices (WoutT: the four 128-column blocks of W_out transposed,
+ * WinT: the four 128-row blocks of W_in transposed, consecutive).  Outputs: d_hV_in, d_gsum, and the operands of the
+ * weight gradients (mpnn_node_wgrad): x1 [n,128], hid = gelu(a) [n,512], d_a [n,512], d_o [n,128], d_dh [n,128];
+ * dvec640 (zero it first) += d ln1_w | d ln1_b | d ln2_w | d ln2_b | d b3. */
+int mpnn_node_update_bwd(const float* dY, const float* dPQ_blocks, const float* x1pre, const float* a_pre,
+                         const float* x2pre, const float* cnt, float cnt_const, const float* mask, const float* ln1_w,
+                         const float* ln1_b, const float* ln2_w, float scale, const float* WprojT_packed, int nproj,
+                         const float* WoutT_packed, const float* WinT_packed, const float* W3T_packed, int n_nodes,
+                         float* d_hV_in, float* d_gsum, float* x1, float* hid, float* d_a, float* d_o, float* d_dh,
+                         float* dvec640, float p_drop, uint32_t drop_seed, void* stream);
+
 /* Weight / bias gradient of an nn.Linear over per-residue rows (autograd of the node-level linears, :78-93, :151-155):
  * dW[o][i] += sum_n dY[n][o] X[n][i]  (row strides ldy, ldx, ldw; fp32 products), dbias[o] += sum_n dY[n][o].
  * Accumulates: zero dW / dbias first.  dbias may be NULL.  workspace: device scratch, 16512 floats per 128x128 output

@@ -52,6 +52,8 @@ SIGNATURES = {
     "mpnn_dec_message_subset": [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I] + [_P] * 8 + [_I] * 4 + [_P, _P],
     "mpnn_node_update_subset": [_P, _P, _F, _P] + [_P] * 10 + [_F, _P, _P, _I, _P, _I, _P, _P, _P],
     "mpnn_sample_subset": [_P, _P, _P, _P, _I, _P, _I, _F, ctypes.c_uint64, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "mpnn_node_update_train": [_P, _P, _P, _F] + [_P] * 11 + [_F, _P, _P, _I, _I] + [_P] * 5 + [_F, ctypes.c_uint32, _P],
+    "mpnn_node_update_bwd": [_P] * 6 + [_F] + [_P] * 4 + [_F, _P, _I, _P, _P, _P, _I] + [_P] * 8 + [_F, ctypes.c_uint32, _P],
     "mpnn_node_wgrad": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P],
 }
 

@@ -7,9 +7,11 @@
 // is split over workgroups; each wave keeps 2 x 8 output tiles in registers, feeds v_mfma_f32_16x16x4_f32 (exact
 // fp32 products) straight from global memory, and stores its partial tile to a workspace that a second small
 // kernel adds up (per-element atomics from every workgroup cost more than the contraction itself).
-#include "mpnn_common.h"
+#include "mpnn_bwd_common.h"
 
 constexpr int NW_PART = 128 * 128 + 128;  // floats of one workgroup partial (tile | bias sums)
+
+namespace {
 
 __global__ void __launch_bounds__(256)
 k_node_wgrad(const float* __restrict__ dY, int ldy, int out_f, const float* __restrict__ X, int ldx, int in_f, int N,
@@ -88,6 +90,343 @@ k_node_wgrad_reduce(const float* __restrict__ part, int nx, int ny, int out_f, i
     const int o = by * 128 + (e - 128 * 128);
     if (o < out_f) unsafeAtomicAdd(db + o, s);
   }
+}
+
+// ---------------------------------------------------------------------------
+// Node update, training form.  Same maths and weight streaming as k_node_update (mpnn_node.hip):
+//   x1pre = h + drop1((W3 gsum + cnt b3) / scale);  x1 = LN1(x1pre);  a = W_in x1 + b_in;
+//   x2pre = x1 + drop2(W_out gelu(a) + b_out);  h' = mask LN2(x2pre);  PQ_p = Wproj_p h' + bproj_p
+// plus: x1pre, a, x2pre are stored for the backward kernel, the two node-level dropouts of the reference's layers
+// (:82, :86, :128, :135) use the counter-based keep decision of mpnn_edge_common.h (ids: node*128+feature, the second
+// dropout with seed ^ 0x5bd1e995), and the projections are written block-major PQ[p][node][128].
+// ---------------------------------------------------------------------------
+constexpr int WSPLIT_N = MPNN_NT * NKK * 2 * 64;
+
+__device__ __forceinline__ void stage_matrix(const h8* __restrict__ g, h8* l) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < WSPLIT_N / 256; ++i) {
+    const int chunk = i * 4 + wave;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + chunk * 64 + lane),
+                                     (__attribute__((address_space(3))) void*)(l + chunk * 64), 16, 0, 0);
+  }
+}
+
+struct DropCfg {
+  unsigned thresh, seed;
+  float inv_keep;
+};
+
+__global__ void __launch_bounds__(256)
+k_node_update_train(const float* __restrict__ hV_in, const float* __restrict__ gsum, const float* __restrict__ cnt,
+                    float cnt_const, const float* __restrict__ mask, const h8* __restrict__ W3,
+                    const float* __restrict__ b3, const float* __restrict__ ln1w, const float* __restrict__ ln1b,
+                    const h8* __restrict__ Win, const float* __restrict__ bin, const h8* __restrict__ Wout,
+                    const float* __restrict__ bout, const float* __restrict__ ln2w, const float* __restrict__ ln2b,
+                    float inv_scale, const h8* __restrict__ Wproj, const float* __restrict__ bproj, int nproj, int N,
+                    float* __restrict__ hV_out, float* __restrict__ PQ, float* __restrict__ s_x1pre,
+                    float* __restrict__ s_a, float* __restrict__ s_x2pre, DropCfg dc) {
+  __shared__ h8 lds[2 * WSPLIT_N];
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int g = lane >> 4, col = lane & 15;
+  const int node = tile * 16 + col;
+  const bool live = node < N;
+  const int nd = live ? node : N - 1;
+  const int nmat = 9 + nproj;
+  auto matrix = [&](int k) -> const h8* {
+    if (k == 0) return W3;
+    if (k < 9) return (((k - 1) & 1) ? Wout : Win) + (size_t)((k - 1) >> 1) * WSPLIT_N;
+    return Wproj + (size_t)(k - 9) * WSPLIT_N;
+  };
+  int k = 0;
+  stage_matrix(matrix(0), lds);
+  auto prefetch = [&]() {
+    if (k + 1 < nmat) stage_matrix(matrix(k + 1), lds + ((k + 1) & 1) * WSPLIT_N);
+  };
+  auto retire = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ++k;
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x4 h[MPNN_NT][1], gs[MPNN_NT][1], dh[MPNN_NT][1];
+  const float cn = cnt ? cnt[nd] : cnt_const;
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) {
+    h[t][0] = *reinterpret_cast<const f32x4*>(hV_in + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+    gs[t][0] = *reinterpret_cast<const f32x4*>(gsum + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+    dh[t][0] = *reinterpret_cast<const f32x4*>(b3 + 16 * t + 4 * g) * cn;
+  }
+  BFrag xb[NKK][1];
+  tile_to_bfrag<MPNN_NT, 1, false>(gs, xb);
+  prefetch();
+  split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT_N + lane, xb, dh);
+  retire();
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) {
+    f32x4 d1 = dh[t][0] * inv_scale;
+    if (dc.thresh) d1 = dropout4(d1, (unsigned)nd * 128u + 16 * t + 4 * g, dc.seed, dc.thresh, dc.inv_keep);
+    h[t][0] += d1;
+    if (live) *reinterpret_cast<f32x4*>(s_x1pre + (size_t)node * MPNN_H + 16 * t + 4 * g) = h[t][0];
+  }
+  tile_layernorm<1>(h, ln1w, ln1b, lane);
+  tile_to_bfrag<MPNN_NT, 1, false>(h, xb);
+  f32x4 o[MPNN_NT][1];
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) o[t][0] = *reinterpret_cast<const f32x4*>(bout + 16 * t + 4 * g);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 hid[MPNN_NT][1];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) hid[t][0] = *reinterpret_cast<const f32x4*>(bin + 128 * q + 16 * t + 4 * g);
+    prefetch();
+    split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT_N + lane, xb, hid);
+    retire();
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+        *reinterpret_cast<f32x4*>(s_a + (size_t)node * 512 + 128 * q + 16 * t + 4 * g) = hid[t][0];
+    }
+    BFrag hb[NKK][1];
+    tile_to_bfrag<MPNN_NT, 1, true>(hid, hb);
+    prefetch();
+    split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT_N + lane, hb, o);
+    retire();
+  }
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) {
+    if (dc.thresh)
+      o[t][0] = dropout4(o[t][0], (unsigned)nd * 128u + 16 * t + 4 * g, dc.seed ^ 0x5bd1e995u, dc.thresh, dc.inv_keep);
+    o[t][0] += h[t][0];
+    if (live) *reinterpret_cast<f32x4*>(s_x2pre + (size_t)node * MPNN_H + 16 * t + 4 * g) = o[t][0];
+  }
+  tile_layernorm<1>(o, ln2w, ln2b, lane);
+  const float mk = mask[nd];
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) {
+    h[t][0] = o[t][0] * mk;
+    if (live) *reinterpret_cast<f32x4*>(hV_out + (size_t)node * MPNN_H + 16 * t + 4 * g) = h[t][0];
+  }
+  BFrag pb[NKK][1];
+  tile_to_bfrag<MPNN_NT, 1, false>(h, pb);
+  for (int p = 0; p < nproj; ++p) {
+    f32x4 y[MPNN_NT][1];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) y[t][0] = *reinterpret_cast<const f32x4*>(bproj + p * MPNN_H + 16 * t + 4 * g);
+    prefetch();
+    split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT_N + lane, pb, y);
+    retire();
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+        *reinterpret_cast<f32x4*>(PQ + ((size_t)p * N + node) * MPNN_H + 16 * t + 4 * g) = y[t][0];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Node update backward.  Streams the TRANSPOSED matrices (projections, then W_out^T / W_in^T per hidden quarter,
+// then W3^T) through the same LDS ring; gradients are power-of-two scaled before the f16 split (grad_to_bfrag).
+//   dy    = mask (dY + sum_p Wproj_p^T dPQ_p)            dx2pre = LN2'(dy; x2pre)        do = drop2'(dx2pre)
+//   da_q  = (W_out_q^T do) gelu'(a_q)                    dx1 = dx2pre + sum_q W_in_q^T da_q
+//   dx1pre = LN1'(dx1; x1pre) = d hV_in                  ddh = drop1'(dx1pre) / scale    dgsum = W3^T ddh
+// Written out for the weight gradients (mpnn_node_wgrad): x1, gelu(a), da, do, ddh.  LayerNorm parameter
+// gradients and db3 = sum_n cnt_n ddh_n are reduced per workgroup in LDS, then added to dvec[0:640]
+// (ln1.w, ln1.b, ln2.w, ln2.b, b3) with one atomic per entry and workgroup.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_node_update_bwd(const float* __restrict__ dY, const float* __restrict__ dPQ, const float* __restrict__ s_x1pre,
+                  const float* __restrict__ s_a, const float* __restrict__ s_x2pre, const float* __restrict__ cnt,
+                  float cnt_const, const float* __restrict__ mask, const float* __restrict__ ln1w,
+                  const float* __restrict__ ln1b, const float* __restrict__ ln2w, float inv_scale,
+                  const h8* __restrict__ WprojT, int nproj, const h8* __restrict__ WoutT, const h8* __restrict__ WinT,
+                  const h8* __restrict__ W3T, int N, float* __restrict__ d_hV_in, float* __restrict__ d_gsum,
+                  float* __restrict__ o_x1, float* __restrict__ o_hid, float* __restrict__ o_da,
+                  float* __restrict__ o_do, float* __restrict__ o_ddh, float* __restrict__ dvec, DropCfg dc) {
+  __shared__ h8 lds[2 * WSPLIT_N];
+  __shared__ float acc1[2 * MPNN_H], acc2[2 * MPNN_H], accb3[MPNN_H];
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int g = lane >> 4, col = lane & 15;
+  const int node = tile * 16 + col;
+  const bool live = node < N;
+  const int nd = live ? node : N - 1;
+  const int nmat = nproj + 9;
+  auto matrix = [&](int k) -> const h8* {
+    if (k < nproj) return WprojT + (size_t)k * WSPLIT_N;
+    k -= nproj;
+    if (k < 8) return ((k & 1) ? WinT : WoutT) + (size_t)(k >> 1) * WSPLIT_N;
+    return W3T;
+  };
+  int k = 0;
+  stage_matrix(matrix(0), lds);
+  auto prefetch = [&]() {
+    if (k + 1 < nmat) stage_matrix(matrix(k + 1), lds + ((k + 1) & 1) * WSPLIT_N);
+  };
+  auto retire = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ++k;
+  };
+  for (int i = threadIdx.x; i < 2 * MPNN_H; i += 256) {
+    acc1[i] = 0.f;
+    acc2[i] = 0.f;
+    if (i < MPNN_H) accb3[i] = 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x4 dy[MPNN_NT][1], x[MPNN_NT][1], tmp[MPNN_NT][1];
+  BFrag bf[NKK][1];
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t)
+    dy[t][0] = dY ? *reinterpret_cast<const f32x4*>(dY + (size_t)nd * MPNN_H + 16 * t + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < nproj; ++p) {
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+      x[t][0] = *reinterpret_cast<const f32x4*>(dPQ + ((size_t)p * N + nd) * MPNN_H + 16 * t + 4 * g);
+    const float un = grad_to_bfrag<1>(x, bf, nullptr);
+    zero_tile<1>(tmp);
+    prefetch();
+    split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT_N + lane, bf, tmp);
+    retire();
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) dy[t][0] += tmp[t][0] * un;
+  }
+  const float mk = live ? mask[nd] : 0.f;  // rows past N contribute nothing to any sum below
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) {
+    dy[t][0] *= mk;
+    x[t][0] = *reinterpret_cast<const f32x4*>(s_x2pre + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+  }
+  tile_layernorm_bwd<1>(x, dy, ln2w, acc2, lane);  // dy <- dx2pre
+  f32x4 dx1[MPNN_NT][1], dob[MPNN_NT][1];
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) {
+    dx1[t][0] = dy[t][0];
+    dob[t][0] = dy[t][0];
+    if (dc.thresh)
+      dob[t][0] = dropout4(dob[t][0], (unsigned)nd * 128u + 16 * t + 4 * g, dc.seed ^ 0x5bd1e995u, dc.thresh, dc.inv_keep);
+    if (live) *reinterpret_cast<f32x4*>(o_do + (size_t)node * MPNN_H + 16 * t + 4 * g) = dob[t][0];
+    x[t][0] = *reinterpret_cast<const f32x4*>(s_x1pre + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+  }
+  tile_layernorm<1>(x, ln1w, ln1b, lane);  // x1, the FFN's input (operand of the W_in gradient)
+  if (live) {
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) *reinterpret_cast<f32x4*>(o_x1 + (size_t)node * MPNN_H + 16 * t + 4 * g) = x[t][0];
+  }
+  BFrag dobf[NKK][1];
+  const float un_o = grad_to_bfrag<1>(dob, dobf, nullptr);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    zero_tile<1>(tmp);
+    prefetch();
+    split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT_N + lane, dobf, tmp);  // W_out_q^T do
+    retire();
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(s_a + (size_t)nd * 512 + 128 * q + 16 * t + 4 * g);
+      tmp[t][0] *= gelu_grad4(a) * un_o;
+      if (live) {
+        *reinterpret_cast<f32x4*>(o_da + (size_t)node * 512 + 128 * q + 16 * t + 4 * g) = tmp[t][0];
+        *reinterpret_cast<f32x4*>(o_hid + (size_t)node * 512 + 128 * q + 16 * t + 4 * g) = gelu4(a);
+      }
+    }
+    const float un = grad_to_bfrag<1>(tmp, bf, nullptr);
+    zero_tile<1>(x);
+    prefetch();
+    split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT_N + lane, bf, x);  // W_in_q^T da_q
+    retire();
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) dx1[t][0] += x[t][0] * un;
+  }
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t)
+    x[t][0] = *reinterpret_cast<const f32x4*>(s_x1pre + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+  tile_layernorm_bwd<1>(x, dx1, ln1w, acc1, lane);  // dx1 <- dx1pre
+  const float cn = cnt ? cnt[nd] : cnt_const;
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) {
+    if (live) *reinterpret_cast<f32x4*>(d_hV_in + (size_t)node * MPNN_H + 16 * t + 4 * g) = dx1[t][0];
+    f32x4 dd = dx1[t][0];
+    if (dc.thresh) dd = dropout4(dd, (unsigned)nd * 128u + 16 * t + 4 * g, dc.seed, dc.thresh, dc.inv_keep);
+    dd *= inv_scale;
+    tmp[t][0] = dd;
+    if (live) *reinterpret_cast<f32x4*>(o_ddh + (size_t)node * MPNN_H + 16 * t + 4 * g) = dd;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = column_sum(dd[r] * cn);
+      if (col == 0) atomicAdd(&accb3[16 * t + 4 * g + r], v);
+    }
+  }
+  const float un = grad_to_bfrag<1>(tmp, bf, nullptr);
+  zero_tile<1>(x);
+  prefetch();
+  split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT_N + lane, bf, x);  // W3^T ddh
+  retire();
+  if (live) {
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+      *reinterpret_cast<f32x4*>(d_gsum + (size_t)node * MPNN_H + 16 * t + 4 * g) = x[t][0] * un;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * MPNN_H; i += 256) {
+    unsafeAtomicAdd(dvec + i, acc1[i]);
+    unsafeAtomicAdd(dvec + 2 * MPNN_H + i, acc2[i]);
+    if (i < MPNN_H) unsafeAtomicAdd(dvec + 4 * MPNN_H + i, accb3[i]);
+  }
+}
+
+}  // namespace
+
+static DropCfg make_drop(float p, uint32_t seed) {
+  DropCfg d;
+  d.thresh = p > 0.f ? (unsigned)((double)p * 4294967296.0) : 0u;
+  d.seed = seed;
+  d.inv_keep = 1.0f / (1.0f - p);
+  return d;
+}
+
+extern "C" int mpnn_node_update_train(const float* hV_in, const float* gsum, const float* cnt, float cnt_const,
+                                      const float* mask, const float* W3_packed, const float* b3, const float* ln1_w,
+                                      const float* ln1_b, const float* Win_packed, const float* b_in,
+                                      const float* Wout_packed, const float* b_out, const float* ln2_w,
+                                      const float* ln2_b, float scale, const float* Wproj_packed, const float* bproj,
+                                      int nproj, int n_nodes, float* hV_out, float* PQ_blocks, float* x1pre, float* a_pre,
+                                      float* x2pre, float p_drop, uint32_t drop_seed, void* stream) {
+  MPNN_CHECK_ARG(hV_in && gsum && mask && W3_packed && b3 && ln1_w && ln1_b && Win_packed && b_in && Wout_packed &&
+                     b_out && ln2_w && ln2_b && hV_out && x1pre && a_pre && x2pre && n_nodes > 0 && nproj >= 0,
+                 "mpnn_node_update_train: bad arguments");
+  MPNN_CHECK_ARG(nproj == 0 || (Wproj_packed && bproj && PQ_blocks), "mpnn_node_update_train: projections need Wproj, bproj, PQ");
+  MPNN_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mpnn_node_update_train: dropout probability must be in [0, 1)");
+  hipLaunchKernelGGL(k_node_update_train, dim3((n_nodes + 63) / 64), dim3(256), 0, (hipStream_t)stream, hV_in, gsum, cnt,
+                     cnt_const, mask, (const h8*)W3_packed, b3, ln1_w, ln1_b, (const h8*)Win_packed, b_in,
+                     (const h8*)Wout_packed, b_out, ln2_w, ln2_b, 1.0f / scale, (const h8*)Wproj_packed, bproj, nproj,
+                     n_nodes, hV_out, PQ_blocks, x1pre, a_pre, x2pre, make_drop(p_drop, drop_seed));
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_node_update_bwd(const float* dY, const float* dPQ_blocks, const float* x1pre, const float* a_pre,
+                                    const float* x2pre, const float* cnt, float cnt_const, const float* mask,
+                                    const float* ln1_w, const float* ln1_b, const float* ln2_w, float scale,
+                                    const float* WprojT_packed, int nproj, const float* WoutT_packed,
+                                    const float* WinT_packed, const float* W3T_packed, int n_nodes, float* d_hV_in,
+                                    float* d_gsum, float* x1, float* hid, float* d_a, float* d_o, float* d_dh,
+                                    float* dvec640, float p_drop, uint32_t drop_seed, void* stream) {
+  MPNN_CHECK_ARG(x1pre && a_pre && x2pre && mask && ln1_w && ln1_b && ln2_w && WoutT_packed && WinT_packed &&
+                     W3T_packed && d_hV_in && d_gsum && x1 && hid && d_a && d_o && d_dh && dvec640 && n_nodes > 0,
+                 "mpnn_node_update_bwd: bad arguments");
+  MPNN_CHECK_ARG(nproj == 0 || (WprojT_packed && dPQ_blocks), "mpnn_node_update_bwd: projections need WprojT and dPQ");
+  MPNN_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mpnn_node_update_bwd: dropout probability must be in [0, 1)");
+  hipLaunchKernelGGL(k_node_update_bwd, dim3((n_nodes + 63) / 64), dim3(256), 0, (hipStream_t)stream, dY, dPQ_blocks,
+                     x1pre, a_pre, x2pre, cnt, cnt_const, mask, ln1_w, ln1_b, ln2_w, 1.0f / scale,
+                     (const h8*)WprojT_packed, nproj, (const h8*)WoutT_packed, (const h8*)WinT_packed,
+                     (const h8*)W3T_packed, n_nodes, d_hV_in, d_gsum, x1, hid, d_a, d_o, d_dh, dvec640,
+                     make_drop(p_drop, drop_seed));
+  MPNN_LAUNCH_CHECK();
 }
 
 extern "C" int mpnn_node_wgrad(const float* dY, int ldy, int out_f, const float* X, int ldx, int in_f, int n_rows,

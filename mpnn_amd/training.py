@@ -10,8 +10,9 @@ What runs where (round 1):
   * neighbour search, backbone atoms, decoding-order ranks: the forward HIP kernels (no gradient flows there);
   * the edge featurizer (RBF / positional embedding -> edge_embedding -> norm_edges -> W_e): forward and backward on
     HIP kernels too (mpnn_edge_features_train / mpnn_edge_features_bwd / mpnn_feature_chunks + mpnn_edge_wgrad);
-  * per-node work (W3, LayerNorm, FFN, projections) and the loss: ATen ops on the same device, differentiated by
-    autograd, with the node-level weight gradients on mpnn_node_wgrad.  A fused HIP node backward is the next step.
+  * per-node work (W3, LayerNorms, FFN, the next kernels' projections): mpnn_node_update_train / mpnn_node_update_bwd,
+    weight gradients on mpnn_node_wgrad; only the occupancy MLP, the sequence-embedding term, the 21-letter head and
+    the loss are ATen ops under autograd.
 There is no CPU path: every tensor must live on the ROCm device.
 """
 from __future__ import annotations
@@ -335,14 +336,107 @@ class FeaturesFn(torch.autograd.Function):
         return (None, None, None, None, None, dT.t().contiguous(), dT.sum(0), dWemb, dln[:H], dln[H:], dWe, dbe)
 
 
-def _node_tail(lyr, hV, gsum, cnt, mask_col, p_drop, training):
-    """dh = (W3 gsum + cnt b3) / scale; norm1; FFN; norm2; mask   (reference :81-89, :127-138)."""
-    dh = (linear(gsum, lyr.W3.weight) + cnt.unsqueeze(-1) * lyr.W3.bias) / lyr.scale
-    hV = lyr.norm1(hV + F.dropout(dh, p_drop, training))
-    ff = linear(F.gelu(linear(hV, lyr.dense.W_in.weight, lyr.dense.W_in.bias)), lyr.dense.W_out.weight,
-                lyr.dense.W_out.bias)
-    hV = lyr.norm2(hV + F.dropout(ff, p_drop, training))
-    return mask_col * hV
+def _pack_any(W, col0=0, ncols=None):
+    """[out, ld] fp32 -> split-packed A fragments of columns col0 .. col0+ncols (out, ncols multiples of 128)."""
+    W = W.detach().contiguous()
+    out_f, ld = W.shape
+    ncols = ld - col0 if ncols is None else ncols
+    out = torch.empty((out_f // 16) * (ncols // 32) * 512, device=W.device, dtype=torch.float32)
+    call("mpnn_pack_linear_split", ptr(W), out_f, ncols, ld, col0, 0, ptr(out), stream_ptr())
+    return out
+
+
+def _node_wgrad(dy, x, want_bias):
+    """dW [out, in] = dy^T x, db = column sums of dy (rows may be strided views with unit inner stride)."""
+    dW = _zeros(dy.device, dy.shape[1], x.shape[1])
+    db = _zeros(dy.device, dy.shape[1]) if want_bias else None
+    ws = _workspace(dy.device)
+    call("mpnn_node_wgrad", ptr(dy), dy.shape[1], dy.shape[1], ptr(x), x.shape[1], x.shape[1], dy.shape[0], ptr(dW),
+         dW.shape[1], ptr(db), ptr(ws), ws.numel(), stream_ptr())
+    return dW, db
+
+
+class NodeUpdateFn(torch.autograd.Function):
+    """h' = mask LN2(x1 + drop(FFN(x1))), x1 = LN1(h + drop((W3 gsum + cnt b3) / scale)), and the next edge kernels'
+    projections Wproj_p h' + b_p   (reference :81-88, :127-137, :151-155; mpnn_node_bwd.hip)."""
+
+    @staticmethod
+    def forward(ctx, meta, hV_in, gsum, cnt, mask, W3, b3, ln1w, ln1b, Win, bin_, Wout, bout, ln2w, ln2b, *projs):
+        dev = hV_in.device
+        N = hV_in.shape[0]
+        nproj = len(projs) // 2
+        scale, p_drop, seed = meta
+        hV_in, gsum = hV_in.contiguous(), gsum.contiguous()
+        w3p, winp = _pack_any(W3), _pack_any(Win)
+        woutp = torch.cat([_pack_any(Wout, H * q, H) for q in range(4)])
+        vec = [v.detach().contiguous() for v in (b3, ln1w, ln1b, bin_, bout, ln2w, ln2b)]
+        wprojp = bproj = PQ = None
+        if nproj:
+            wprojp = torch.cat([_pack_any(projs[2 * p]) for p in range(nproj)])
+            bproj = torch.zeros(nproj * H, device=dev, dtype=torch.float32)
+            for p in range(nproj):
+                if projs[2 * p + 1] is not None:
+                    bproj[p * H:(p + 1) * H] = projs[2 * p + 1].detach()
+            PQ = torch.empty(nproj, N, H, device=dev, dtype=torch.float32)
+        hV_out = torch.empty(N, H, device=dev, dtype=torch.float32)
+        x1pre, x2pre = torch.empty_like(hV_out), torch.empty_like(hV_out)
+        a_pre = torch.empty(N, 4 * H, device=dev, dtype=torch.float32)
+        call("mpnn_node_update_train", ptr(hV_in), ptr(gsum), ptr(cnt), 0.0, ptr(mask), ptr(w3p), ptr(vec[0]), ptr(vec[1]),
+             ptr(vec[2]), ptr(winp), ptr(vec[3]), ptr(woutp), ptr(vec[4]), ptr(vec[5]), ptr(vec[6]), float(scale),
+             ptr(wprojp), ptr(bproj), nproj, N, ptr(hV_out), ptr(PQ), ptr(x1pre), ptr(a_pre), ptr(x2pre), float(p_drop),
+             int(seed), stream_ptr())
+        ctx.meta, ctx.nproj = meta, nproj
+        ctx.has_bias = [projs[2 * p + 1] is not None for p in range(nproj)]
+        ctx.save_for_backward(gsum, cnt, mask, W3, ln1w, ln1b, Win, Wout, ln2w, hV_out, x1pre, a_pre, x2pre,
+                              *[projs[2 * p] for p in range(nproj)])
+        return (hV_out,) + tuple(PQ[p] for p in range(nproj))
+
+    @staticmethod
+    def backward(ctx, dY, *dPQ):
+        scale, p_drop, seed = ctx.meta
+        nproj = ctx.nproj
+        gsum, cnt, mask, W3, ln1w, ln1b, Win, Wout, ln2w, hV_out, x1pre, a_pre, x2pre = ctx.saved_tensors[:13]
+        Wp = ctx.saved_tensors[13:]
+        dev = gsum.device
+        N = gsum.shape[0]
+        dY = dY.contiguous() if dY is not None else None
+        dPQb = wprojT = None
+        if nproj:
+            dPQb = torch.stack([d if d is not None else torch.zeros(N, H, device=dev) for d in dPQ])
+            wprojT = torch.cat([_pack_any(W.detach().t()) for W in Wp])
+        woutT = _pack_any(Wout.detach().t())                                           # [512,128]: 4 row blocks
+        WinT = Win.detach().t().contiguous()                                           # [128,512]
+        winT = torch.cat([_pack_any(WinT, H * q, H) for q in range(4)])
+        w3T = _pack_any(W3.detach().t())
+        d_hV_in, d_gsum = torch.empty(N, H, device=dev), torch.empty(N, H, device=dev)
+        x1, d_o, d_dh = torch.empty(N, H, device=dev), torch.empty(N, H, device=dev), torch.empty(N, H, device=dev)
+        hid, d_a = torch.empty(N, 4 * H, device=dev), torch.empty(N, 4 * H, device=dev)
+        dvec = _zeros(dev, 5 * H)
+        call("mpnn_node_update_bwd", ptr(dY), ptr(dPQb), ptr(x1pre), ptr(a_pre), ptr(x2pre), ptr(cnt), 0.0, ptr(mask),
+             ptr(ln1w.detach().contiguous()), ptr(ln1b.detach().contiguous()), ptr(ln2w.detach().contiguous()),
+             float(scale), ptr(wprojT), nproj, ptr(woutT), ptr(winT), ptr(w3T), N, ptr(d_hV_in), ptr(d_gsum), ptr(x1),
+             ptr(hid), ptr(d_a), ptr(d_o), ptr(d_dh), ptr(dvec), float(p_drop), int(seed), stream_ptr())
+        dW3, _ = _node_wgrad(d_dh, gsum, False)
+        dWin, dbin = _node_wgrad(d_a, x1, True)
+        dWout, dbout = _node_wgrad(d_o, hid, True)
+        grads = [None, d_hV_in, d_gsum, None, None, dW3, dvec[4 * H:], dvec[:H], dvec[H:2 * H], dWin, dbin, dWout, dbout,
+                 dvec[2 * H:3 * H], dvec[3 * H:4 * H]]
+        for p in range(nproj):
+            dWp, dbp = _node_wgrad(dPQb[p], hV_out, ctx.has_bias[p])
+            grads += [dWp, dbp]
+        return tuple(grads)
+
+
+def _node_update(lyr, hV, gsum, cnt, mask, p_drop, projs):
+    """projs: list of (weight view [128,128], bias | None) -> (h', [projection tensors])."""
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0  # host generator: no device sync
+    flat = []
+    for W, b in projs:
+        flat += [W, b]
+    out = NodeUpdateFn.apply((float(lyr.scale), float(p_drop), seed), hV, gsum, cnt, mask, lyr.W3.weight, lyr.W3.bias,
+                             lyr.norm1.weight, lyr.norm1.bias, lyr.dense.W_in.weight, lyr.dense.W_in.bias,
+                             lyr.dense.W_out.weight, lyr.dense.W_out.bias, lyr.norm2.weight, lyr.norm2.bias, *flat)
+    return out[0], list(out[1:])
 
 
 def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order=None,
@@ -357,8 +451,7 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
     residue_idx, chain_labels = engine._i64(residue_idx), engine._i64(chain_encoding_all)
     fm = model.features
     training = model.training
-    p_drop = float(model.dropout_p)
-    p_edge = p_drop if training else 0.0
+    p_drop = float(model.dropout_p) if training else 0.0
     _ZEROS.reset(dev)  # gradient accumulators of this step's backward pass
     with torch.no_grad():
         atoms, _, E_idx64, E_idx32, _, edge_mask, K = engine._geometry(fm, X, mask, fix_backbone_noise, training)
@@ -373,20 +466,33 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
     hV = torch.zeros(N, H, device=dev, dtype=torch.float32)
     if model.occupancy_mlp is not None and occ is not None:
         hV = hV + model.occupancy_mlp(occ.view(N, 1))
-    mcol = g.mask.view(N, 1)
+    enc, dec = list(model.encoder_layers), list(model.decoder_layers)
 
-    for lyr in model.encoder_layers:
+    def msg_blocks(lyr):      # P = W1a h + b1, Q = W1c h
+        return [(lyr.W1.weight[:, :H], lyr.W1.bias), (lyr.W1.weight[:, 2 * H:3 * H], None)]
+
+    def dec_first_blocks():   # Pa_0, A_0 (without the sequence term), the encoder rows of every decoder layer
+        if not dec:
+            return []
+        return ([(dec[0].W1.weight[:, :H], dec[0].W1.bias), (dec[0].W1.weight[:, 3 * H:], None)] +
+                [(d_.W1.weight[:, 3 * H:], None) for d_ in dec])
+
+    first = msg_blocks(enc[0]) if enc else dec_first_blocks()
+    proj = [linear(hV, W, b) for W, b in first]
+    for l, lyr in enumerate(enc):
         W1, W11 = lyr.W1.weight, lyr.W11.weight
-        P, Q = linear(hV, W1[:, :H], lyr.W1.bias), linear(hV, W1[:, 2 * H:])
-        gsum, cnt = MessageFn.apply(g, slot, False, hE, P, Q, None, W1[:, H:2 * H], lyr.W2.weight, lyr.W2.bias)
-        hV = _node_tail(lyr, hV, gsum, cnt, mcol, p_drop, training)
-        P, Q = linear(hV, W11[:, :H], lyr.W11.bias), linear(hV, W11[:, 2 * H:])
-        drop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_edge > 0 else 0  # host generator: no sync
-        hE = EdgeUpdateFn.apply(g, slot, p_edge, drop_seed, hE, P, Q, W11[:, H:2 * H], lyr.W12.weight, lyr.W12.bias, lyr.W13.weight,
-                                lyr.W13.bias, lyr.norm3.weight, lyr.norm3.bias)
+        gsum, cnt = MessageFn.apply(g, slot, False, hE, proj[0], proj[1], None, W1[:, H:2 * H], lyr.W2.weight,
+                                    lyr.W2.bias)
+        nxt = msg_blocks(enc[l + 1]) if l + 1 < len(enc) else dec_first_blocks()
+        hV, proj = _node_update(lyr, hV, gsum, cnt, g.mask, p_drop,
+                                [(W11[:, :H], lyr.W11.bias), (W11[:, 2 * H:3 * H], None)] + nxt)
+        drop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
+        hE = EdgeUpdateFn.apply(g, slot, p_drop, drop_seed, hE, proj[0], proj[1], W11[:, H:2 * H], lyr.W12.weight,
+                                lyr.W12.bias, lyr.W13.weight, lyr.W13.bias, lyr.norm3.weight, lyr.norm3.bias)
         slot = GradSlot()
+        proj = proj[2:]
 
-    if len(model.decoder_layers):
+    if dec:
         with torch.no_grad():
             cm = engine._f32(chain_M) * mask
             if fix_order is not None:
@@ -397,14 +503,16 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
             call("mpnn_order_rank", ptr(order), B, L, ptr(rank), stream_ptr())
             g.set_order(rank)
         hS = model.W_s(S.reshape(-1))
-        hV_enc = hV
-        for lyr in model.decoder_layers:
+        Pa, A0, Benc = proj[0], proj[1], proj[2:]
+        for l, lyr in enumerate(dec):
             W1 = lyr.W1.weight
-            Pa = linear(hV, W1[:, :H], lyr.W1.bias)
-            A = linear(hV, W1[:, 3 * H:]) + linear(hS, W1[:, 2 * H:3 * H])
-            Benc = linear(hV_enc, W1[:, 3 * H:])
-            gsum, cnt = MessageFn.apply(g, slot, True, hE, Pa, A, Benc, W1[:, H:2 * H], lyr.W2.weight, lyr.W2.bias)
-            hV = _node_tail(lyr, hV, gsum, cnt, mcol, p_drop, training)
+            A = A0 + linear(hS, W1[:, 2 * H:3 * H])      # sequence term W1c W_s[S] of the decoded neighbours
+            gsum, cnt = MessageFn.apply(g, slot, True, hE, Pa, A, Benc[l], W1[:, H:2 * H], lyr.W2.weight, lyr.W2.bias)
+            nxt = [(dec[l + 1].W1.weight[:, :H], dec[l + 1].W1.bias), (dec[l + 1].W1.weight[:, 3 * H:], None)] \
+                if l + 1 < len(dec) else []
+            hV, pr = _node_update(lyr, hV, gsum, cnt, g.mask, p_drop, nxt)
+            if pr:
+                Pa, A0 = pr
     logits = linear(hV, model.W_out.weight, model.W_out.bias)
     return F.log_softmax(logits, dim=-1).view(B, L, -1)
 
