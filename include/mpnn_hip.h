@@ -176,10 +176,13 @@ int mpnn_enc_edge_update_bwd(const float* dy_frag, const float* z_frag, const fl
 int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax, const float* B_frag, int b_gelu, int n_nodes,
                     int K, float* dW, float* dbias, float* workspace, int workspace_floats, void* stream);
 
-/* Gradient of the neighbour gather h[E_idx]: outA[j] = sum of rows[inv_row[m]] for m in [inv_ptr[j], inv_ptr[j+1]),
- * split between outA (sel[m] == 0) and outB (sel[m] != 0) when sel is given (decoder: which block the edge read). */
+/* Gradient of the neighbour gather h[E_idx]: outA[j] += sum of rows[inv_row[m]] for m in [inv_ptr[j], inv_ptr[j+1]),
+ * split between outA (sel[m] == 0) and outB (sel[m] != 0) when sel is given (decoder: which block the edge read).
+ * Work unit = a chunk of <= 32 list entries: chunk_ptr[j] = sum_{i<j} ceil(degree_i / 32) (n_nodes + 1 entries),
+ * max_chunks >= chunk_ptr[n_nodes] (n_edges / 32 + n_nodes always suffices).  Outputs are accumulated with atomics:
+ * zero them first. */
 int mpnn_gather_rows(const float* rows, const int32_t* inv_ptr, const int32_t* inv_row, const unsigned char* sel,
-                     int n_nodes, float* outA, float* outB, void* stream);
+                     const int32_t* chunk_ptr, int n_nodes, int max_chunks, float* outA, float* outB, void* stream);
 
 /* Training forward of mpnn_edge_features: also stores the pre-LayerNorm embedding E0 and E = norm_edges(E0), both in
  * the fragment layout, for mpnn_edge_features_bwd / mpnn_edge_wgrad (:334-358, :464). */
@@ -224,6 +227,12 @@ int mpnn_node_update_bwd(const float* dY, const float* dPQ_blocks, const float* 
                          const float* WoutT_packed, const float* WinT_packed, const float* W3T_packed, int n_nodes,
                          float* d_hV_in, float* d_gsum, float* x1, float* hid, float* d_a, float* d_o, float* d_dh,
                          float* dvec640, float p_drop, uint32_t drop_seed, void* stream);
+
+/* mpnn_pack_linear_split for n 128x128 blocks in one launch per 16 blocks: block b is read at blocks[b] with row
+ * stride ld[b] (out[o][i] = W[o * ld + i]), or transposed (out[o][i] = W[i * ld + o]) when transposed[b] != 0, and
+ * written to packed + b * 16384 floats.  blocks / ld / transposed are HOST arrays of device pointers / ints. */
+int mpnn_pack_blocks(const float* const* blocks, const int* ld, const int* transposed, int n, float* packed,
+                     void* stream);
 
 /* Weight / bias gradient of an nn.Linear over per-residue rows (autograd of the node-level linears, :78-93, :151-155):
  * dW[o][i] += sum_n dY[n][o] X[n][i]  (row strides ldy, ldx, ldw; fp32 products), dbias[o] += sum_n dY[n][o].

@@ -44,7 +44,7 @@ SIGNATURES = {
     "mpnn_message_bwd": [_I] + [_P] * 8 + [_I] * 3 + [_P] * 4 + [_I, _P, _P],
     "mpnn_enc_edge_update_bwd": [_P] * 8 + [_I] * 3 + [_P] * 7 + [_F, ctypes.c_uint32, _P],
     "mpnn_edge_wgrad": [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P],
-    "mpnn_gather_rows": [_P] * 4 + [_I] + [_P] * 3,
+    "mpnn_gather_rows": [_P] * 5 + [_I, _I] + [_P] * 3,
     "mpnn_edge_features_train": [_P] * 11 + [_I, _I, _I, _I, _P, _P, _P, _P],
     "mpnn_edge_features_bwd": [_P] * 4 + [_I] * 3 + [_P] * 4,
     "mpnn_feature_chunks": [_P] * 5 + [_I] * 4 + [_P, _P],
@@ -54,6 +54,7 @@ SIGNATURES = {
     "mpnn_sample_subset": [_P, _P, _P, _P, _I, _P, _I, _F, ctypes.c_uint64, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "mpnn_node_update_train": [_P, _P, _P, _F] + [_P] * 11 + [_F, _P, _P, _I, _I] + [_P] * 5 + [_F, ctypes.c_uint32, _P],
     "mpnn_node_update_bwd": [_P] * 6 + [_F] + [_P] * 4 + [_F, _P, _I, _P, _P, _P, _I] + [_P] * 8 + [_F, ctypes.c_uint32, _P],
+    "mpnn_pack_blocks": [_P, _P, _P, _I, _P, _P],
     "mpnn_node_wgrad": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P],
 }
 

@@ -384,17 +384,30 @@ k_wgrad_reduce(const float* __restrict__ part, int nparts, float* __restrict__ d
 }
 
 // ---------------------------------------------------------------------------
-// out[j] = sum of the rows listed for node j (inverse neighbour list: rows that gathered node j in forward).
+// out[j] += sum of the rows listed for node j (inverse neighbour list: rows that gathered node j in forward).
 // sel (optional, per list entry): 0 -> outA, 1 -> outB  (decoder: row came from the A or the encoder block)
-// One wave per destination node, 512-byte coalesced row reads, eight rows in flight.
+// In-degrees are very uneven (hub residues are gathered by hundreds of neighbours), so the unit of work is a CHUNK
+// of at most 32 list entries: wave w finds its (node, chunk) by binary search in chunk_ptr (prefix sum of
+// ceil(degree / 32)), reads its rows as coalesced 512-byte lines (8 in flight) and adds its partial sum to the
+// zero-initialised outputs with fp32 atomics.
 // ---------------------------------------------------------------------------
+constexpr int GATHER_CHUNK = 32;
+
 __global__ void __launch_bounds__(256)
 k_gather_rows(const float* __restrict__ rows, const int* __restrict__ inv_ptr, const int* __restrict__ inv_row,
-              const unsigned char* __restrict__ sel, int N, float* __restrict__ outA, float* __restrict__ outB) {
+              const unsigned char* __restrict__ sel, const int* __restrict__ chunk_ptr, int N, int n_waves,
+              float* __restrict__ outA, float* __restrict__ outB) {
   const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (j >= N) return;
-  const int m0 = inv_ptr[j], m1 = inv_ptr[j + 1];
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_waves || w >= chunk_ptr[N]) return;
+  int lo = 0, hi = N;  // largest j with chunk_ptr[j] <= w
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_ptr[mid] <= w) lo = mid; else hi = mid;
+  }
+  const int j = lo;
+  const int m0 = inv_ptr[j] + (w - chunk_ptr[j]) * GATHER_CHUNK;
+  const int m1 = min(inv_ptr[j + 1], m0 + GATHER_CHUNK);
   float2 sa = make_float2(0.f, 0.f), sb = sa;
   int m = m0;
   for (; m + 8 <= m1; m += 8) {
@@ -414,8 +427,14 @@ k_gather_rows(const float* __restrict__ rows, const int* __restrict__ inv_ptr, c
     const float2 v = *reinterpret_cast<const float2*>(rows + (size_t)inv_row[m] * MPNN_H + 2 * lane);
     if (sel && sel[m]) { sb.x += v.x; sb.y += v.y; } else { sa.x += v.x; sa.y += v.y; }
   }
-  *reinterpret_cast<float2*>(outA + (size_t)j * MPNN_H + 2 * lane) = sa;
-  if (outB) *reinterpret_cast<float2*>(outB + (size_t)j * MPNN_H + 2 * lane) = sb;
+  float* oa = outA + (size_t)j * MPNN_H + 2 * lane;
+  unsafeAtomicAdd(oa, sa.x);
+  unsafeAtomicAdd(oa + 1, sa.y);
+  if (outB) {
+    float* ob = outB + (size_t)j * MPNN_H + 2 * lane;
+    unsafeAtomicAdd(ob, sb.x);
+    unsafeAtomicAdd(ob + 1, sb.y);
+  }
 }
 
 // ===========================================================================
@@ -503,11 +522,12 @@ extern "C" int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax
 }
 
 extern "C" int mpnn_gather_rows(const float* rows, const int32_t* inv_ptr, const int32_t* inv_row,
-                                const unsigned char* sel, int n_nodes, float* outA, float* outB, void* stream) {
-  MPNN_CHECK_ARG(rows && inv_ptr && inv_row && outA, "mpnn_gather_rows: null pointer");
-  MPNN_CHECK_ARG(n_nodes > 0 && (!sel || outB), "mpnn_gather_rows: a selector needs the second output");
-  hipLaunchKernelGGL(k_gather_rows, dim3((n_nodes + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, inv_ptr, inv_row,
-                     sel, n_nodes, outA, outB);
+                                const unsigned char* sel, const int32_t* chunk_ptr, int n_nodes, int max_chunks,
+                                float* outA, float* outB, void* stream) {
+  MPNN_CHECK_ARG(rows && inv_ptr && inv_row && chunk_ptr && outA, "mpnn_gather_rows: null pointer");
+  MPNN_CHECK_ARG(n_nodes > 0 && max_chunks > 0 && (!sel || outB), "mpnn_gather_rows: a selector needs the second output");
+  hipLaunchKernelGGL(k_gather_rows, dim3((max_chunks + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, inv_ptr, inv_row,
+                     sel, chunk_ptr, n_nodes, max_chunks, outA, outB);
   MPNN_LAUNCH_CHECK();
 }
 

@@ -382,6 +382,60 @@ k_node_update_bwd(const float* __restrict__ dY, const float* __restrict__ dPQ, c
 
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// Batched split packing of 128x128 blocks (training re-packs every weight each step: one launch per kernel call
+// instead of one per matrix).  Block b: out[o][i] = W_b[o * ld_b + i], or W_b[i * ld_b + o] when transposed; the
+// descriptors travel as a by-value kernel argument.
+// ---------------------------------------------------------------------------
+constexpr int PACK_MAX = 16;
+struct PackBatch {
+  const float* W[PACK_MAX];
+  int ld[PACK_MAX];
+  int transposed[PACK_MAX];
+};
+
+namespace {
+__global__ void __launch_bounds__(256)
+k_pack_blocks(PackBatch pb, h8* __restrict__ packed) {
+  const int b = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // (to, kk, lane): 8 * 4 * 64
+  const int lane = idx & 63, kk = (idx >> 6) & 3, to = idx >> 8;
+  const int row = 16 * to + (lane & 15);
+  const float* W = pb.W[b];
+  const int ld = pb.ld[b], tr = pb.transposed[b];
+  h8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int col = 16 * (2 * kk + (j >> 2)) + 4 * (lane >> 4) + (j & 3);
+    const float w = tr ? W[(size_t)col * ld + row] : W[(size_t)row * ld + col];
+    const _Float16 h = (_Float16)w;
+    hi[j] = h;
+    lo[j] = (_Float16)(w - (float)h);
+  }
+  h8* dst = packed + (size_t)b * WSPLIT_N;
+  dst[((to * 4 + kk) * 2 + 0) * 64 + lane] = hi;
+  dst[((to * 4 + kk) * 2 + 1) * 64 + lane] = lo;
+}
+}  // namespace
+
+extern "C" int mpnn_pack_blocks(const float* const* blocks, const int* ld, const int* transposed, int n, float* packed,
+                                void* stream) {
+  MPNN_CHECK_ARG(blocks && ld && transposed && packed && n > 0, "mpnn_pack_blocks: bad arguments");
+  for (int i0 = 0; i0 < n; i0 += PACK_MAX) {
+    PackBatch pb;
+    const int m = n - i0 < PACK_MAX ? n - i0 : PACK_MAX;
+    for (int i = 0; i < PACK_MAX; ++i) {
+      pb.W[i] = blocks[i0 + (i < m ? i : 0)];
+      pb.ld[i] = ld[i0 + (i < m ? i : 0)];
+      pb.transposed[i] = transposed[i0 + (i < m ? i : 0)];
+    }
+    MPNN_CHECK_ARG(pb.W[0] != nullptr, "mpnn_pack_blocks: null block");
+    hipLaunchKernelGGL(k_pack_blocks, dim3(8, m), dim3(256), 0, (hipStream_t)stream, pb,
+                       (h8*)packed + (size_t)i0 * WSPLIT_N);
+  }
+  MPNN_LAUNCH_CHECK();
+}
+
 static DropCfg make_drop(float p, uint32_t seed) {
   DropCfg d;
   d.thresh = p > 0.f ? (unsigned)((double)p * 4294967296.0) : 0u;

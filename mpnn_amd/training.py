@@ -50,6 +50,9 @@ class Graph:
         # (torch.bincount synchronises with the host to size its output; scatter_add does not)
         counts = torch.zeros(self.N, device=dev, dtype=torch.int64).scatter_add_(0, self.dest, torch.ones_like(self.dest))
         self.inv_ptr = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]).to(torch.int32).contiguous()
+        chunks = (counts + 31) // 32  # mpnn_gather_rows works on chunks of <= 32 list entries (hub residues!)
+        self.chunk_ptr = torch.cat([chunks.new_zeros(1), torch.cumsum(chunks, 0)]).to(torch.int32).contiguous()
+        self.max_chunks = (self.N * K) // 32 + self.N
         self.rank = None
         self.sel = None
 
@@ -64,12 +67,20 @@ class Graph:
         return self.N * 8 * self.KT * 256
 
 
-def _pack_split(W):
-    """[128,128] fp32 (contiguous) -> f16 hi/lo A-fragment packing."""
-    W = W.detach().contiguous()
-    out = torch.empty(16384, device=W.device, dtype=torch.float32)
-    call("mpnn_pack_linear_split", ptr(W), H, H, H, 0, 0, ptr(out), stream_ptr())
-    return out
+def _pack_blocks(blocks):
+    """blocks: list of (view [128,128] with unit inner stride, transposed?) -> list of packed [16384] tensors
+    (f16 hi/lo A fragments), all produced by one launch per 16 blocks (mpnn_pack_blocks)."""
+    import ctypes
+    n = len(blocks)
+    views = [b[0].detach() for b in blocks]
+    for v in views:
+        assert v.shape == (H, H) and v.stride(1) == 1, "pack blocks must be 128x128 with unit inner stride"
+    out = torch.empty(n * 16384, device=views[0].device, dtype=torch.float32)
+    ptrs = (ctypes.c_void_p * n)(*[v.data_ptr() for v in views])
+    lds = (ctypes.c_int * n)(*[v.stride(0) for v in views])
+    trs = (ctypes.c_int * n)(*[1 if b[1] else 0 for b in blocks])
+    call("mpnn_pack_blocks", ptrs, lds, trs, n, ptr(out), stream_ptr())
+    return [out[i * 16384:(i + 1) * 16384] for i in range(n)]
 
 
 def _wgrad(A, a_rows, amax, Bfrag, b_gelu, g, want_bias):
@@ -82,10 +93,10 @@ def _wgrad(A, a_rows, amax, Bfrag, b_gelu, g, want_bias):
 
 
 def _gather(rows, g, sel):
-    outA = torch.empty(g.N, H, device=rows.device, dtype=torch.float32)
-    outB = torch.empty_like(outA) if sel is not None else None
-    call("mpnn_gather_rows", ptr(rows), ptr(g.inv_ptr), ptr(g.inv_row), ptr(sel), g.N, ptr(outA), ptr(outB),
-         stream_ptr())
+    outA = torch.zeros(g.N, H, device=rows.device, dtype=torch.float32)
+    outB = torch.zeros_like(outA) if sel is not None else None
+    call("mpnn_gather_rows", ptr(rows), ptr(g.inv_ptr), ptr(g.inv_row), ptr(sel), ptr(g.chunk_ptr), g.N, g.max_chunks,
+         ptr(outA), ptr(outB), stream_ptr())
     return outA, outB
 
 
@@ -185,7 +196,7 @@ class MessageFn(torch.autograd.Function):
         a1 = torch.empty(g.frag_numel(), device=dev, dtype=torch.float32)
         a2 = torch.empty_like(a1)
         b2c = b2.detach().contiguous()
-        w1p, w2p = _pack_split(W1b), _pack_split(W2)  # named: a temporary's block could be reused before the launch
+        w1p, w2p = _pack_blocks([(W1b, False), (W2, False)])  # named: a temporary's block could be reused before the launch
         call("mpnn_message_train", int(dec), ptr(hE), ptr(P), ptr(RowA), ptr(RowB), ptr(g.rank) if dec else None,
              ptr(g.E_idx32), ptr(g.mask), ptr(g.edge_mask), ptr(w1p), ptr(w2p), ptr(b2c),
              g.B, g.L, g.K, ptr(gsum), ptr(cnt), ptr(a1), ptr(a2), stream_ptr())
@@ -210,7 +221,7 @@ class MessageFn(torch.autograd.Function):
         if first:
             slot.buf = torch.empty_like(a1)
         dE = slot.buf
-        w2t, w1t = _pack_split(W2.detach().t()), _pack_split(W1b.detach().t())
+        w2t, w1t = _pack_blocks([(W2, True), (W1b, True)])
         amax = _zeros(dev, 2)
         call("mpnn_message_bwd", int(dec), ptr(dgsum), ptr(a1), ptr(a2), ptr(g.E_idx32), ptr(g.mask), ptr(g.edge_mask),
              ptr(w2t), ptr(w1t), g.B, g.L, g.K, ptr(da2), ptr(rows),
@@ -231,7 +242,7 @@ class EdgeUpdateFn(torch.autograd.Function):
         out = torch.empty_like(hE)
         a1, a2, z = torch.empty_like(hE), torch.empty_like(hE), torch.empty_like(hE)
         vec = [t.detach().contiguous() for t in (b12, b13, lnw, lnb)]
-        w1p, w2p, w3p = _pack_split(W11b), _pack_split(W12), _pack_split(W13)
+        w1p, w2p, w3p = _pack_blocks([(W11b, False), (W12, False), (W13, False)])
         call("mpnn_enc_edge_update_train", ptr(hE), ptr(P), ptr(Q), ptr(g.E_idx32), ptr(w1p),
              ptr(w2p), ptr(vec[0]), ptr(w3p), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), g.B, g.L,
              g.K, ptr(out), ptr(a1), ptr(a2), ptr(z), float(p_drop), int(seed), stream_ptr())
@@ -252,7 +263,7 @@ class EdgeUpdateFn(torch.autograd.Function):
         dP = torch.empty(g.N, H, device=dev, dtype=torch.float32)
         dln = _zeros(dev, 2 * H)
         amax = _zeros(dev, 3)
-        w3t, w2t, w1t = _pack_split(W13.detach().t()), _pack_split(W12.detach().t()), _pack_split(W11b.detach().t())
+        w3t, w2t, w1t = _pack_blocks([(W13, True), (W12, True), (W11b, True)])
         call("mpnn_enc_edge_update_bwd", ptr(dy), ptr(z), ptr(a2), ptr(a1), ptr(lnw.detach().contiguous()),
              ptr(w3t), ptr(w2t), ptr(w1t),
              g.B, g.L, g.K, ptr(dz), ptr(da2), ptr(rows), ptr(dP), ptr(dE), ptr(dln), ptr(amax), ctx.drop[0], ctx.drop[1], stream_ptr())
@@ -295,7 +306,7 @@ class FeaturesFn(torch.autograd.Function):
         nkk = (Wc.shape[1] + 31) // 32
         Wemb_p = torch.empty(8 * nkk * 512, device=dev, dtype=torch.float32)
         call("mpnn_pack_linear_split", ptr(Wc), H, Wc.shape[1], Wc.shape[1], 0, 16, ptr(Wemb_p), st)
-        We_p = _pack_split(We)
+        We_p, = _pack_blocks([(We, False)])
         vec = [t.detach().contiguous() for t in (lnw, lnb, be)]
         hE = torch.empty(g.frag_numel(), device=dev, dtype=torch.float32)
         E0, E = torch.empty_like(hE), torch.empty_like(hE)
@@ -316,7 +327,7 @@ class FeaturesFn(torch.autograd.Function):
         dE0 = torch.empty_like(E0)
         dln = _zeros(dev, 2 * H)
         amax = _zeros(dev, 2)
-        wet = _pack_split(We.detach().t())
+        wet, = _pack_blocks([(We, True)])
         call("mpnn_edge_features_bwd", ptr(dhE), ptr(E0), ptr(lnw.detach().contiguous()), ptr(wet), g.B, g.L, g.K,
              ptr(dE0), ptr(dln), ptr(amax), st)
         dWe, dbe = _wgrad(dhE, False, amax[0:1], E, False, g, True)
@@ -334,16 +345,6 @@ class FeaturesFn(torch.autograd.Function):
         dT = G.t() @ W[:, :npos]                                            # gradient of the 66 x 16 embedding table
         dWemb = torch.cat([G @ table.view(66, 16), dF[:, :nrbf]], dim=1)
         return (None, None, None, None, None, dT.t().contiguous(), dT.sum(0), dWemb, dln[:H], dln[H:], dWe, dbe)
-
-
-def _pack_any(W, col0=0, ncols=None):
-    """[out, ld] fp32 -> split-packed A fragments of columns col0 .. col0+ncols (out, ncols multiples of 128)."""
-    W = W.detach().contiguous()
-    out_f, ld = W.shape
-    ncols = ld - col0 if ncols is None else ncols
-    out = torch.empty((out_f // 16) * (ncols // 32) * 512, device=W.device, dtype=torch.float32)
-    call("mpnn_pack_linear_split", ptr(W), out_f, ncols, ld, col0, 0, ptr(out), stream_ptr())
-    return out
 
 
 def _node_wgrad(dy, x, want_bias):
@@ -367,12 +368,15 @@ class NodeUpdateFn(torch.autograd.Function):
         nproj = len(projs) // 2
         scale, p_drop, seed = meta
         hV_in, gsum = hV_in.contiguous(), gsum.contiguous()
-        w3p, winp = _pack_any(W3), _pack_any(Win)
-        woutp = torch.cat([_pack_any(Wout, H * q, H) for q in range(4)])
+        pk = _pack_blocks([(W3, False)] + [(Win[H * q:H * (q + 1)], False) for q in range(4)] +
+                          [(Wout[:, H * q:H * (q + 1)], False) for q in range(4)] +
+                          [(projs[2 * p], False) for p in range(nproj)])
+        base = pk[0]._base if pk[0]._base is not None else pk[0]  # consecutive blocks of one buffer
+        w3p, winp, woutp = pk[0], base[16384:5 * 16384], base[5 * 16384:9 * 16384]
         vec = [v.detach().contiguous() for v in (b3, ln1w, ln1b, bin_, bout, ln2w, ln2b)]
         wprojp = bproj = PQ = None
         if nproj:
-            wprojp = torch.cat([_pack_any(projs[2 * p]) for p in range(nproj)])
+            wprojp = base[9 * 16384:]
             bproj = torch.zeros(nproj * H, device=dev, dtype=torch.float32)
             for p in range(nproj):
                 if projs[2 * p + 1] is not None:
@@ -403,11 +407,12 @@ class NodeUpdateFn(torch.autograd.Function):
         dPQb = wprojT = None
         if nproj:
             dPQb = torch.stack([d if d is not None else torch.zeros(N, H, device=dev) for d in dPQ])
-            wprojT = torch.cat([_pack_any(W.detach().t()) for W in Wp])
-        woutT = _pack_any(Wout.detach().t())                                           # [512,128]: 4 row blocks
-        WinT = Win.detach().t().contiguous()                                           # [128,512]
-        winT = torch.cat([_pack_any(WinT, H * q, H) for q in range(4)])
-        w3T = _pack_any(W3.detach().t())
+        pk = _pack_blocks([(W, True) for W in Wp] + [(Wout[:, H * q:H * (q + 1)], True) for q in range(4)] +
+                          [(Win[H * q:H * (q + 1)], True) for q in range(4)] + [(W3, True)])
+        base = pk[0]._base if pk[0]._base is not None else pk[0]
+        o = nproj * 16384
+        wprojT = base[:o] if nproj else None
+        woutT, winT, w3T = base[o:o + 4 * 16384], base[o + 4 * 16384:o + 8 * 16384], base[o + 8 * 16384:o + 9 * 16384]
         d_hV_in, d_gsum = torch.empty(N, H, device=dev), torch.empty(N, H, device=dev)
         x1, d_o, d_dh = torch.empty(N, H, device=dev), torch.empty(N, H, device=dev), torch.empty(N, H, device=dev)
         hid, d_a = torch.empty(N, 4 * H, device=dev), torch.empty(N, 4 * H, device=dev)
