@@ -323,6 +323,12 @@ int mpnn_node_update_subset_f16(const float* hV_in, const float* gsum, float cnt
                             const float* bproj, int nproj, const int32_t* node_list, int n_list, float* hV_out,
                             float* PQ, void* stream);
 
+/* mpnn_node_wgrad for up to 12 linears over the same n_rows in ONE launch (all linears of one node update).  Every
+ * array argument is a HOST array with one entry per job (device pointers / ints); dbias[j] may be NULL. */
+int mpnn_node_wgrad_batch(int n_jobs, const float* const* dY, const int* ldy, const int* out_f, const float* const* X,
+                          const int* ldx, const int* in_f, float* const* dW, const int* ldw, float* const* dbias,
+                          int n_rows, float* workspace, int workspace_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

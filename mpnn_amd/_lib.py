@@ -54,6 +54,7 @@ SIGNATURES = {
     "mpnn_sample_subset": [_P, _P, _P, _P, _I, _P, _I, _F, ctypes.c_uint64, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "mpnn_node_update_train": [_P, _P, _P, _F] + [_P] * 11 + [_F, _P, _P, _I, _I] + [_P] * 5 + [_F, ctypes.c_uint32, _P],
     "mpnn_node_update_bwd": [_P] * 6 + [_F] + [_P] * 4 + [_F, _P, _I, _P, _P, _P, _I] + [_P] * 8 + [_F, ctypes.c_uint32, _P],
+    "mpnn_node_wgrad_batch": [_I] + [_P] * 9 + [_I, _P, _I, _P],
     "mpnn_pack_blocks": [_P, _P, _P, _I, _P, _P],
     "mpnn_node_wgrad": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P],
 }

@@ -11,14 +11,36 @@
 
 constexpr int NW_PART = 128 * 128 + 128;  // floats of one workgroup partial (tile | bias sums)
 
+// up to WG_JOBS weight gradients over the same rows in one launch (all linears of one node update): the job table
+// travels by value; blockIdx.y enumerates the 128x128 output blocks of all jobs (job j owns blk0[j] .. blk0[j+1])
+constexpr int WG_JOBS = 12;
+struct WgradJobs {
+  const float* dY[WG_JOBS];
+  const float* X[WG_JOBS];
+  float* dW[WG_JOBS];
+  float* db[WG_JOBS];
+  int ldy[WG_JOBS], out_f[WG_JOBS], ldx[WG_JOBS], in_f[WG_JOBS], ldw[WG_JOBS], ny[WG_JOBS], blk0[WG_JOBS + 1];
+  int n;
+};
+
 namespace {
 
+__device__ __forceinline__ int find_job(const WgradJobs& jb, int blk) {
+  int j = 0;
+  while (j + 1 < jb.n && blk >= jb.blk0[j + 1]) ++j;
+  return j;
+}
+
 __global__ void __launch_bounds__(256)
-k_node_wgrad(const float* __restrict__ dY, int ldy, int out_f, const float* __restrict__ X, int ldx, int in_f, int N,
-             int rows_per_wg, float* __restrict__ part) {
+k_node_wgrad(WgradJobs jb, int N, int rows_per_wg, float* __restrict__ part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, col = lane & 15;
-  const int o0 = blockIdx.y * 128 + 32 * wave, i0 = blockIdx.z * 128;
+  const int job = find_job(jb, blockIdx.y);
+  const int local = blockIdx.y - jb.blk0[job];
+  const float* __restrict__ dY = jb.dY[job];
+  const float* __restrict__ X = jb.X[job];
+  const int ldy = jb.ldy[job], out_f = jb.out_f[job], ldx = jb.ldx[job], in_f = jb.in_f[job];
+  const int o0 = (local % jb.ny[job]) * 128 + 32 * wave, i0 = (local / jb.ny[job]) * 128;
   const int r0 = blockIdx.x * rows_per_wg;
   const int r1 = min(N, r0 + rows_per_wg);
   f32x4 acc[2][8];
@@ -58,7 +80,7 @@ k_node_wgrad(const float* __restrict__ dY, int ldy, int out_f, const float* __re
       }
   }
   // partial tile of this workgroup -> workspace; k_node_wgrad_reduce adds the row chunks up
-  float* P = part + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW_PART;
+  float* P = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NW_PART;
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -74,11 +96,15 @@ k_node_wgrad(const float* __restrict__ dY, int ldy, int out_f, const float* __re
 
 // dW block (blockIdx.y, blockIdx.z) += sum over row chunks of the partial tiles; chunk slices meet by atomics
 __global__ void __launch_bounds__(256)
-k_node_wgrad_reduce(const float* __restrict__ part, int nx, int ny, int out_f, int in_f, float* __restrict__ dW, int ldw,
-                    float* __restrict__ db) {
+k_node_wgrad_reduce(const float* __restrict__ part, int nx, WgradJobs jb) {
   const int e = blockIdx.x * 256 + threadIdx.x;  // element of the 128x128 (+128 bias) partial
   const int slice = blockIdx.y % 4, blk = blockIdx.y / 4;
-  const int by = blk % ny, bz = blk / ny;
+  const int job = find_job(jb, blk);
+  const int local = blk - jb.blk0[job];
+  const int by = local % jb.ny[job], bz = local / jb.ny[job];
+  const int out_f = jb.out_f[job], in_f = jb.in_f[job], ldw = jb.ldw[job];
+  float* __restrict__ dW = jb.dW[job];
+  float* __restrict__ db = jb.db[job];
   if (e >= NW_PART) return;
   const float* P = part + (size_t)blk * nx * NW_PART + e;
   float s = 0.f;
@@ -483,20 +509,51 @@ extern "C" int mpnn_node_update_bwd(const float* dY, const float* dPQ_blocks, co
   MPNN_LAUNCH_CHECK();
 }
 
+static int launch_node_wgrads(const WgradJobs& jb, int n_rows, float* workspace, int workspace_floats, hipStream_t st) {
+  const int nblk = jb.blk0[jb.n];
+  const int max_x = workspace_floats / NW_PART / nblk;
+  MPNN_CHECK_ARG(max_x >= 1, "mpnn_node_wgrad: workspace too small (16512 floats per 128x128 block and row chunk)");
+  int rows = 32;  // rows per workgroup: as many row chunks as the workspace and ~256 workgroups per block allow
+  while ((n_rows + rows - 1) / rows > (max_x < 256 ? max_x : 256)) rows *= 2;
+  const int nx = (n_rows + rows - 1) / rows;
+  hipLaunchKernelGGL(k_node_wgrad, dim3(nx, nblk), dim3(256), 0, st, jb, n_rows, rows, workspace);
+  hipLaunchKernelGGL(k_node_wgrad_reduce, dim3((NW_PART + 255) / 256, 4 * nblk), dim3(256), 0, st, workspace, nx, jb);
+  MPNN_LAUNCH_CHECK();
+}
+
 extern "C" int mpnn_node_wgrad(const float* dY, int ldy, int out_f, const float* X, int ldx, int in_f, int n_rows,
                                float* dW, int ldw, float* dbias, float* workspace, int workspace_floats, void* stream) {
   MPNN_CHECK_ARG(dY && X && dW && workspace, "mpnn_node_wgrad: null pointer");
   MPNN_CHECK_ARG(n_rows > 0 && out_f > 0 && in_f > 0 && ldy >= out_f && ldx >= in_f && ldw >= in_f,
                  "mpnn_node_wgrad: bad sizes");
-  const int ny = (out_f + 127) / 128, nz = (in_f + 127) / 128;
-  const int max_x = workspace_floats / NW_PART / (ny * nz);
-  MPNN_CHECK_ARG(max_x >= 1, "mpnn_node_wgrad: workspace too small (16512 floats per 128x128 block and row chunk)");
-  int rows = 32;  // rows per workgroup: as many row chunks as the workspace and ~256 workgroups per block allow
-  while ((n_rows + rows - 1) / rows > (max_x < 256 ? max_x : 256)) rows *= 2;
-  const int nx = (n_rows + rows - 1) / rows;
-  hipLaunchKernelGGL(k_node_wgrad, dim3(nx, ny, nz), dim3(256), 0, (hipStream_t)stream, dY, ldy, out_f, X, ldx, in_f,
-                     n_rows, rows, workspace);
-  hipLaunchKernelGGL(k_node_wgrad_reduce, dim3((NW_PART + 255) / 256, 4 * ny * nz), dim3(256), 0, (hipStream_t)stream,
-                     workspace, nx, ny, out_f, in_f, dW, ldw, dbias);
-  MPNN_LAUNCH_CHECK();
+  WgradJobs jb = {};
+  jb.n = 1;
+  jb.dY[0] = dY; jb.X[0] = X; jb.dW[0] = dW; jb.db[0] = dbias;
+  jb.ldy[0] = ldy; jb.out_f[0] = out_f; jb.ldx[0] = ldx; jb.in_f[0] = in_f; jb.ldw[0] = ldw;
+  jb.ny[0] = (out_f + 127) / 128;
+  jb.blk0[0] = 0;
+  jb.blk0[1] = jb.ny[0] * ((in_f + 127) / 128);
+  return launch_node_wgrads(jb, n_rows, workspace, workspace_floats, (hipStream_t)stream);
+}
+
+extern "C" int mpnn_node_wgrad_batch(int n_jobs, const float* const* dY, const int* ldy, const int* out_f,
+                                     const float* const* X, const int* ldx, const int* in_f, float* const* dW,
+                                     const int* ldw, float* const* dbias, int n_rows, float* workspace,
+                                     int workspace_floats, void* stream) {
+  MPNN_CHECK_ARG(dY && ldy && out_f && X && ldx && in_f && dW && ldw && dbias && workspace && n_rows > 0,
+                 "mpnn_node_wgrad_batch: null pointer");
+  MPNN_CHECK_ARG(n_jobs >= 1 && n_jobs <= WG_JOBS, "mpnn_node_wgrad_batch: 1 .. 12 jobs per call");
+  WgradJobs jb = {};
+  jb.n = n_jobs;
+  jb.blk0[0] = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    MPNN_CHECK_ARG(dY[j] && X[j] && dW[j] && out_f[j] > 0 && in_f[j] > 0 && ldy[j] >= out_f[j] && ldx[j] >= in_f[j] &&
+                       ldw[j] >= in_f[j],
+                   "mpnn_node_wgrad_batch: bad job");
+    jb.dY[j] = dY[j]; jb.X[j] = X[j]; jb.dW[j] = dW[j]; jb.db[j] = dbias[j];
+    jb.ldy[j] = ldy[j]; jb.out_f[j] = out_f[j]; jb.ldx[j] = ldx[j]; jb.in_f[j] = in_f[j]; jb.ldw[j] = ldw[j];
+    jb.ny[j] = (out_f[j] + 127) / 128;
+    jb.blk0[j + 1] = jb.blk0[j] + jb.ny[j] * ((in_f[j] + 127) / 128);
+  }
+  return launch_node_wgrads(jb, n_rows, workspace, workspace_floats, (hipStream_t)stream);
 }

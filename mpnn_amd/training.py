@@ -357,6 +357,21 @@ def _node_wgrad(dy, x, want_bias):
     return dW, db
 
 
+def _node_wgrad_batch(jobs):
+    """jobs: list of (dy [N,out], x [N,in], want_bias) sharing N -> list of (dW, db | None); one launch."""
+    import ctypes
+    n = len(jobs)
+    dev = jobs[0][0].device
+    outs = [(_zeros(dev, dy.shape[1], x.shape[1]), _zeros(dev, dy.shape[1]) if wb else None) for dy, x, wb in jobs]
+    vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
+    ws = _workspace(dev)
+    call("mpnn_node_wgrad_batch", n, vp(*[ptr(j[0]) for j in jobs]), ip(*[j[0].shape[1] for j in jobs]),
+         ip(*[j[0].shape[1] for j in jobs]), vp(*[ptr(j[1]) for j in jobs]), ip(*[j[1].shape[1] for j in jobs]),
+         ip(*[j[1].shape[1] for j in jobs]), vp(*[ptr(o[0]) for o in outs]), ip(*[o[0].shape[1] for o in outs]),
+         vp(*[ptr(o[1]) for o in outs]), jobs[0][0].shape[0], ptr(ws), ws.numel(), stream_ptr())
+    return outs
+
+
 class NodeUpdateFn(torch.autograd.Function):
     """h' = mask LN2(x1 + drop(FFN(x1))), x1 = LN1(h + drop((W3 gsum + cnt b3) / scale)), and the next edge kernels'
     projections Wproj_p h' + b_p   (reference :81-88, :127-137, :151-155; mpnn_node_bwd.hip)."""
@@ -421,13 +436,12 @@ class NodeUpdateFn(torch.autograd.Function):
              ptr(ln1w.detach().contiguous()), ptr(ln1b.detach().contiguous()), ptr(ln2w.detach().contiguous()),
              float(scale), ptr(wprojT), nproj, ptr(woutT), ptr(winT), ptr(w3T), N, ptr(d_hV_in), ptr(d_gsum), ptr(x1),
              ptr(hid), ptr(d_a), ptr(d_o), ptr(d_dh), ptr(dvec), float(p_drop), int(seed), stream_ptr())
-        dW3, _ = _node_wgrad(d_dh, gsum, False)
-        dWin, dbin = _node_wgrad(d_a, x1, True)
-        dWout, dbout = _node_wgrad(d_o, hid, True)
+        res = _node_wgrad_batch([(d_dh, gsum, False), (d_a, x1, True), (d_o, hid, True)] +
+                                [(dPQb[p], hV_out, ctx.has_bias[p]) for p in range(nproj)])
+        (dW3, _), (dWin, dbin), (dWout, dbout) = res[:3]
         grads = [None, d_hV_in, d_gsum, None, None, dW3, dvec[4 * H:], dvec[:H], dvec[H:2 * H], dWin, dbin, dWout, dbout,
                  dvec[2 * H:3 * H], dvec[3 * H:4 * H]]
-        for p in range(nproj):
-            dWp, dbp = _node_wgrad(dPQb[p], hV_out, ctx.has_bias[p])
+        for dWp, dbp in res[3:]:
             grads += [dWp, dbp]
         return tuple(grads)
 
