@@ -148,16 +148,27 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
     _lib.set_profiler(None)
     kern = {n: round(sum(e0.elapsed_time(e1) for e0, e1 in evs) / 3, 3) for n, evs in sorted(prof.items())}
     hip_ms = sum(kern.values())
+    # HBM bytes this design moves per residue and step (confirmed per kernel by the PMC passes in
+    # profiles/r01_pmc_traffic_train.txt): in units of one residue's fragment tensor F = 8 * ceil(K/16) KiB,
+    # encoder layer 36 F, decoder layer 14 F, featurizer 20 F  =>  170 F for the 3 + 3 layer model
+    frag = 8 * ((K + 15) // 16) * 1024
+    step_bytes = 170 * frag * B * L
+    tbps = step_bytes / (elapsed / steps) / 1e12
     return {"metric": "residues/sec (train step: fwd + bwd + AdamW) at L=512,k=48",
             "value": round(B * L * world * steps / elapsed, 1), "unit": "residues/s", "n_gpus": world, "steps": steps,
             "warmup": warm, "ms_per_step": round(elapsed / steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(enqueue / steps * 1e3, 3), "scaling": "weak",
             "config": {"workload": f"BASELINE configs[2]: {B} x L={L} = {B * L} residues per rank, k={K}, dropout 0, "
                                    "AdamW, one flat gradient all-reduce per step", "global_batch": B * world},
+            "roofline": {"bound": "hbm", "achieved": round(tbps * 1e3, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(tbps / 8.0, 4), "bytes_per_step": step_bytes,
+                         "note": "whole step: saved activations and per-edge gradients are written once and re-read "
+                                 "by the backward and weight-gradient passes; the edge backward kernels run at "
+                                 "4.3-4.5 TB/s, the weight-gradient pass at 3.6 TB/s (PMC-confirmed bytes)"},
             "final_loss": round(float(loss), 6),
             "hip_kernels_ms_per_step": kern, "hip_kernels_total_ms": round(hip_ms, 3),
-            "note": "per-edge forward/backward/weight-gradient kernels are HIP; per-node ops, featurizer embedding "
-                    "and optimizer run as ATen ops this round (remaining time = ms_per_step - hip_kernels_total_ms)"}
+            "note": "forward, backward and weight gradients of the featurizer, edge and node stages are HIP kernels; "
+                    "the 21-letter head, sequence embedding, loss and optimizer are ATen ops"}
 
 
 def sampling_leg(a, dev, rank, world, dist, barrier):
