@@ -164,9 +164,10 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
       for (int c = 0; c < KT; ++c) {
-        dE[off + (t * KT + c) * 64] = d[t][c];
-        if (drop_thresh)
+        if (drop_thresh) {  // without dropout dz_out itself serves the residual at the end: one tensor write less
+          dE[off + (t * KT + c) * 64] = d[t][c];
           d[t][c] = dropout4(d[t][c], (unsigned)(off + (t * KT + c) * 64) * 4u, drop_seed, drop_thresh, inv_keep);
+        }
         dz_out[off + (t * KT + c) * 64] = d[t][c];
       }
     BFrag db[NKK][KT];
@@ -199,7 +200,10 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-      for (int c = 0; c < KT; ++c) dE[off + (t * KT + c) * 64] = x[t][c] * un + dE[off + (t * KT + c) * 64];
+      for (int c = 0; c < KT; ++c) {
+        const f32x4 res = drop_thresh ? dE[off + (t * KT + c) * 64] : dz_out[off + (t * KT + c) * 64];
+        dE[off + (t * KT + c) * 64] = x[t][c] * un + res;
+      }
   }
   __syncthreads();
   if (threadIdx.x < 2 * MPNN_H) unsafeAtomicAdd(dln + threadIdx.x, lnacc[threadIdx.x]);
@@ -270,6 +274,23 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 constexpr int WG_PART = MPNN_H * MPNN_H + MPNN_H;  // floats of one workgroup partial (dW | dbias)
 constexpr int WG_LDK = 52;  // padded edge stride (halves): 104-byte rows spread the 8-byte operand reads over banks
 
+// 4x4 transpose across a lane quad: out[j] of quad lane i = in[i] of quad lane j (two DPP exchange stages)
+__device__ __forceinline__ f32x4 quad_transpose(f32x4 v) {
+  const int lane = threadIdx.x;
+  const bool odd = lane & 1, hi = lane & 2;
+  auto xchg = [](float x, int ctrl) {
+    return __int_as_float(ctrl == 0xB1 ? __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false)
+                                       : __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false));
+  };
+  // stage 1: lanes i <-> i^1 swap the low index bit
+  float r01 = xchg(odd ? v.x : v.y, 0xB1), r23 = xchg(odd ? v.z : v.w, 0xB1);
+  if (odd) { v.x = r01; v.z = r23; } else { v.y = r01; v.w = r23; }
+  // stage 2: lanes i <-> i^2 swap the high index bit
+  float r02 = xchg(hi ? v.x : v.z, 0x4E), r13 = xchg(hi ? v.y : v.w, 0x4E);
+  if (hi) { v.x = r02; v.y = r13; } else { v.z = r02; v.w = r13; }
+  return v;
+}
+
 template <bool A_NAT, bool B_GELU>
 __global__ void __launch_bounds__(256)
 k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigned* __restrict__ amax, int N, int KT,
@@ -319,14 +340,23 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
           if (B_GELU) b = gelu4(b);
           bacc[tt] += a;
           a *= sc;
+          // registers hold 4 features of one edge; the MFMA operand rows want 4 edges of one feature: transpose the
+          // 4x4 block held by each lane quad (DPP), then one 8-byte LDS write per plane instead of four 2-byte ones
+          a = quad_transpose(a);
+          b = quad_transpose(b);
+          h4 ah, al, bh, bl;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const _Float16 ah = (_Float16)a[r], bh = (_Float16)b[r];
-            sA[0][16 * t + 4 * g + r][16 * c + col] = ah;
-            sA[1][16 * t + 4 * g + r][16 * c + col] = (_Float16)(a[r] - (float)ah);
-            sB[0][16 * t + 4 * g + r][16 * c + col] = bh;
-            sB[1][16 * t + 4 * g + r][16 * c + col] = (_Float16)(b[r] - (float)bh);
+            ah[r] = (_Float16)a[r];
+            al[r] = (_Float16)(a[r] - (float)ah[r]);
+            bh[r] = (_Float16)b[r];
+            bl[r] = (_Float16)(b[r] - (float)bh[r]);
           }
+          const int frow = 16 * t + 4 * g + (col & 3), ecol = 16 * c + 4 * (col >> 2);
+          *reinterpret_cast<h4*>(&sA[0][frow][ecol]) = ah;
+          *reinterpret_cast<h4*>(&sA[1][frow][ecol]) = al;
+          *reinterpret_cast<h4*>(&sB[0][frow][ecol]) = bh;
+          *reinterpret_cast<h4*>(&sB[1][frow][ecol]) = bl;
         }
       }
     }
