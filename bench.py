@@ -114,7 +114,8 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
     gc.collect()
     gc.freeze()
     torch.manual_seed(1234)
-    model = ProteinMPNN(k_neighbors=K, augment_eps=0.0, dropout=0.0).train().to(dev)
+    # the reference's training defaults (train.py:199-211): dropout 0.1 (node- and edge-level), backbone noise 0.1 A
+    model = ProteinMPNN(k_neighbors=K, augment_eps=0.1, dropout=0.1).train().to(dev)
     if world > 1:
         distributed.broadcast_parameters(model.parameters())
     # AdamW(lr, weight_decay=1e-2) as train.py:217; the fused multi-tensor implementation is the same update in one launch
@@ -124,7 +125,7 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
     steps, warm = max(3, min(a.steps, 10)), 2
 
     def step():
-        return training.train_step(model, opt, batch, world_size=world, fix_order=b["fix_order"])
+        return training.train_step(model, opt, batch, world_size=world)
 
     for _ in range(warm):
         step()
@@ -158,8 +159,9 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
             "value": round(B * L * world * steps / elapsed, 1), "unit": "residues/s", "n_gpus": world, "steps": steps,
             "warmup": warm, "ms_per_step": round(elapsed / steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(enqueue / steps * 1e3, 3), "scaling": "weak",
-            "config": {"workload": f"BASELINE configs[2]: {B} x L={L} = {B * L} residues per rank, k={K}, dropout 0, "
-                                   "AdamW, one flat gradient all-reduce per step", "global_batch": B * world},
+            "config": {"workload": f"BASELINE configs[2]: {B} x L={L} = {B * L} residues per rank, k={K}, dropout 0.1, "
+                                   "backbone noise 0.1, random decoding order per step, AdamW, one flat gradient "
+                                   "all-reduce per step", "global_batch": B * world},
             "roofline": {"bound": "hbm", "achieved": round(tbps * 1e3, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(tbps / 8.0, 4), "bytes_per_step": step_bytes,
                          "note": "whole step: saved activations and per-edge gradients are written once and re-read "
