@@ -251,15 +251,17 @@ int mpnn_node_wgrad(const float* dY, int ldy, int out_f, const float* X, int ldx
  * ------------------------------------------------------------------------------------------------------------ */
 
 /* mpnn_dec_message for the residues in node_list: hE / E_idx32 / edge_mask / PVenc are indexed with
- * (residue % enc_nodes); P, RowA, rank, mask, gsum with the residue id. */
+ * (residue % enc_nodes); P, RowA, rank, mask, gsum with the residue id.  One wave per (residue, 16-neighbour tile);
+ * the partial sums are ADDED to gsum with atomics: the listed gsum rows must be zero on entry. */
 int mpnn_dec_message_subset(const float* hE_frag, const float* P, int ldp, int offP, const float* RowA, int lda,
                             int offA, const float* PVenc, int ldenc, int offEnc, const int32_t* rank,
                             const int32_t* E_idx32, const float* mask, const float* edge_mask, const float* W1b_packed,
                             const float* W2_packed, const float* b2, const int32_t* node_list, int n_list,
                             int enc_nodes, int L, int K, float* gsum, void* stream);
 
-/* mpnn_node_update (do_update = 1, cnt = cnt_const, no table add) for the residues in node_list. */
-int mpnn_node_update_subset(const float* hV_in, const float* gsum, float cnt_const, const float* mask,
+/* mpnn_node_update (do_update = 1, cnt = cnt_const, no table add) for the residues in node_list; sets the gsum rows it
+ * has read back to zero, ready for the next level's accumulation. */
+int mpnn_node_update_subset(const float* hV_in, float* gsum, float cnt_const, const float* mask,
                             const float* W3_packed, const float* b3, const float* ln1_w, const float* ln1_b,
                             const float* Win_packed, const float* b_in, const float* Wout_packed, const float* b_out,
                             const float* ln2_w, const float* ln2_b, float scale, const float* Wproj_packed,
@@ -316,7 +318,7 @@ int mpnn_dec_message_subset_f16(const float* hE_frag, const float* P, int ldp, i
                             const float* W2_packed, const float* b2, const int32_t* node_list, int n_list,
                             int enc_nodes, int L, int K, float* gsum, void* stream);
 
-int mpnn_node_update_subset_f16(const float* hV_in, const float* gsum, float cnt_const, const float* mask,
+int mpnn_node_update_subset_f16(const float* hV_in, float* gsum, float cnt_const, const float* mask,
                             const float* W3_packed, const float* b3, const float* ln1_w, const float* ln1_b,
                             const float* Win_packed, const float* b_in, const float* Wout_packed, const float* b_out,
                             const float* ln2_w, const float* ln2_b, float scale, const float* Wproj_packed,

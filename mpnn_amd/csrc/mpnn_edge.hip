@@ -475,6 +475,80 @@ k_message_tiles(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, in
   }
 }
 
+// ---------------------------------------------------------------------------
+// decoder message for the sampler's dependency levels: a level holds only a few hundred residues, so the unit of
+// work is one COLUMN TILE (16 neighbours) of one listed residue per wave - three times the parallelism of the
+// residue-per-wave kernels and a third of their latency, which is what bounds a level.  Partial neighbour sums
+// meet in gsum by fp32 atomics (gsum rows must be zero on entry; mpnn_node_update_subset re-zeroes what it reads).
+// Indexing as k_message's SUB mode: encoder-side arrays by (residue % enc_mod).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(MPNN_MSGT_WAVES * 64)
+k_message_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp, int offP,
+                const float* __restrict__ Abuf, int lda, int offA, const float* __restrict__ Bbuf, int ldb, int offB,
+                const int* __restrict__ rank, const int* __restrict__ E_idx, const float* __restrict__ mask,
+                const float* __restrict__ edge_mask, const h8* __restrict__ W1b, const h8* __restrict__ W2,
+                const float* __restrict__ b2, const int* __restrict__ node_list, int n_list, int enc_mod, int L, int K,
+                int KT, float* __restrict__ gsum) {
+  __shared__ h8 lds[2 * WSPLIT];
+  lds_fill(lds, W1b, WSPLIT);
+  lds_fill(lds + WSPLIT, W2, WSPLIT);
+  __syncthreads();
+  const h8* W1s = lds;
+  const h8* W2s = lds + WSPLIT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  const int Kp = KT * 16;
+  const int stride = gridDim.x * MPNN_MSGT_WAVES;
+  for (int item = blockIdx.x * MPNN_MSGT_WAVES + wave; item < n_list * KT; item += stride) {
+    LAUNDER(b2);
+    const int node = node_list[item / KT], c = item % KT;
+    const int sh = node % enc_mod, b = node / L;
+    const int e = 16 * c + col;
+    const int jl = E_idx[(size_t)sh * Kp + e];
+    const int jn = b * L + jl;
+    float em = 1.0f;
+    if (edge_mask && e < K) em = edge_mask[(size_t)sh * K + e];
+    const bool before = rank[node] > rank[jn];
+    const float* row = before ? (Abuf + (size_t)jn * lda + offA + 4 * g)
+                              : (Bbuf + (size_t)((sh / L) * L + jl) * ldb + offB + 4 * g);
+    const float sc = mask[node] * em;
+    const float w = e < K ? 1.0f : 0.0f;
+    const float* Pi = Pbuf + (size_t)node * ldp + offP + 4 * g;
+    const f32x4* x = hE + ((size_t)sh * MPNN_NT * KT + c) * 64 + lane;
+    f32x4 xt[MPNN_NT], h1[MPNN_NT][1];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      xt[t] = x[(size_t)t * KT * 64];
+      h1[t][0] = row_tile(row, t);
+    }
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      BFrag bf[1];
+      split_pair(xt[2 * kk], xt[2 * kk + 1], bf[0]);
+      split_kstep<1, NKK, 0, MPNN_NT>(W1s, kk, lane, bf, h1);
+    }
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) h1[t][0] = h1[t][0] * sc + row_tile(Pi, t);
+    BFrag hb[NKK][1];
+    tile_to_bfrag<MPNN_NT, 1, true>(h1, hb);
+    f32x4 y[MPNN_NT][1];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) y[t][0] = *reinterpret_cast<const f32x4*>(b2 + 16 * t + 4 * g);
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) split_kstep<1, NKK, 0, MPNN_NT>(W2s, kk, lane, hb[kk], y);
+    float* gout = gsum + (size_t)node * MPNN_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      f32x4 sm = gelu4(y[t][0]) * w;
+      sm.x = column_sum(sm.x); sm.y = column_sum(sm.y); sm.z = column_sum(sm.z); sm.w = column_sum(sm.w);
+      if (col == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(gout + 16 * t + r, sm[r]);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -614,12 +688,9 @@ extern "C" int MPNN_API(mpnn_dec_message_subset)(const float* hE_frag, const flo
                      mult4(ldp, offP, lda, offA, ldenc, offEnc),
                  "mpnn_dec_message_subset: bad sizes (K <= 48; strides/offsets multiples of 4 floats)");
   const int KT = (K + 15) / 16;
-  dim3 grid(edge_grid(n_list, MPNN_MSG_WAVES)), block(MPNN_MSG_WAVES * 64);
-  KT_DISPATCH(KT > 3 ? 3 : KT,
-              hipLaunchKernelGGL((k_message<(kKT > 3 ? 3 : kKT), true, false, true>), grid, block, 0,
-                                 (hipStream_t)stream, (const f32x4*)hE_frag, P, ldp, offP, RowA, lda, offA, PVenc, ldenc,
-                                 offEnc, rank, E_idx32, mask, edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2,
-                                 n_list, L, K, gsum, (float*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr, node_list,
-                                 enc_nodes));
+  dim3 grid(edge_grid(n_list * KT, MPNN_MSGT_WAVES)), block(MPNN_MSGT_WAVES * 64);
+  hipLaunchKernelGGL(k_message_level, grid, block, 0, (hipStream_t)stream, (const f32x4*)hE_frag, P, ldp, offP, RowA, lda,
+                     offA, PVenc, ldenc, offEnc, rank, E_idx32, mask, edge_mask, (const h8*)W1b_packed,
+                     (const h8*)W2_packed, b2, node_list, n_list, enc_nodes, L, K, KT, gsum);
   MPNN_LAUNCH_CHECK();
 }

@@ -142,6 +142,100 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
   }
 }
 
+// ---------------------------------------------------------------------------
+// node update for the sampler's dependency levels (a few hundred listed residues per launch): latency, not
+// throughput, matters, so the 11 matrix stages of k_node_update are spread over the 4 waves of a 16-node workgroup:
+//   W3 by output-tile pairs, the FFN by hidden quarters (W_in_q and W_out_q per wave), the projections by halves;
+// partial results meet through a 32 KiB LDS exchange buffer, weights stream straight from L2.  Same maths as
+// k_node_update (cnt = cnt_const, no table add); reads AND RE-ZEROES its gsum rows (k_message_level accumulates).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_node_update_level(const float* __restrict__ hV_in, float* __restrict__ gsum, float cnt_const,
+                    const float* __restrict__ mask, const h8* __restrict__ W3, const float* __restrict__ b3,
+                    const float* __restrict__ ln1w, const float* __restrict__ ln1b, const h8* __restrict__ Win,
+                    const float* __restrict__ bin, const h8* __restrict__ Wout, const float* __restrict__ bout,
+                    const float* __restrict__ ln2w, const float* __restrict__ ln2b, float inv_scale,
+                    const h8* __restrict__ Wproj, const float* __restrict__ bproj, int nproj,
+                    const int* __restrict__ node_list, int n_list, float* __restrict__ hV_out, float* __restrict__ PQ) {
+  __shared__ f32x4 ex[4][MPNN_NT][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  const int idx = blockIdx.x * 16 + col;
+  const bool live = idx < n_list;
+  const int nd = node_list[live ? idx : n_list - 1];
+
+  f32x4 h[MPNN_NT][1], gs[MPNN_NT][1];
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) {
+    h[t][0] = *reinterpret_cast<const f32x4*>(hV_in + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+    gs[t][0] = *reinterpret_cast<const f32x4*>(gsum + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+  }
+  BFrag xb[NKK][1];
+  tile_to_bfrag<MPNN_NT, 1, false>(gs, xb);
+  {  // ---- W3: this wave's two output tiles
+    f32x4 d2[2][1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) d2[i][0] = *reinterpret_cast<const f32x4*>(b3 + 16 * (2 * wave + i) + 4 * g) * cnt_const;
+    split_gemm_stream<1, NKK, 2, 3>(W3 + (size_t)(2 * wave) * NKK * 2 * 64 + lane, xb, d2);
+    ex[0][2 * wave][lane] = d2[0][0];
+    ex[0][2 * wave + 1][lane] = d2[1][0];
+  }
+  __syncthreads();
+  if (wave == 0 && live) {
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+      *reinterpret_cast<f32x4*>(gsum + (size_t)nd * MPNN_H + 16 * t + 4 * g) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) h[t][0] += ex[0][t][lane] * inv_scale;
+  tile_layernorm<1>(h, ln1w, ln1b, lane);
+  tile_to_bfrag<MPNN_NT, 1, false>(h, xb);
+  f32x4 o[MPNN_NT][1];
+  {  // ---- FFN: hidden quarter `wave`
+    f32x4 hid[MPNN_NT][1];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      hid[t][0] = *reinterpret_cast<const f32x4*>(bin + 128 * wave + 16 * t + 4 * g);
+      o[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    split_gemm_stream<1, NKK, MPNN_NT, 3>(Win + (size_t)wave * WSPLIT + lane, xb, hid);
+    BFrag hb[NKK][1];
+    tile_to_bfrag<MPNN_NT, 1, true>(hid, hb);
+    split_gemm_stream<1, NKK, MPNN_NT, 3>(Wout + (size_t)wave * WSPLIT + lane, hb, o);
+  }
+  __syncthreads();  // every wave has read the W3 exchange
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) ex[wave][t][lane] = o[t][0];
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t)
+    o[t][0] = h[t][0] + *reinterpret_cast<const f32x4*>(bout + 16 * t + 4 * g) +
+              ((ex[0][t][lane] + ex[1][t][lane]) + (ex[2][t][lane] + ex[3][t][lane]));
+  tile_layernorm<1>(o, ln2w, ln2b, lane);
+  const float mk = mask[nd];
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) {
+    h[t][0] = o[t][0] * mk;
+    if (live && wave == 0) *reinterpret_cast<f32x4*>(hV_out + (size_t)nd * MPNN_H + 16 * t + 4 * g) = h[t][0];
+  }
+  // ---- projections, one half (4 output tiles) per wave at a time
+  BFrag pb[NKK][1];
+  tile_to_bfrag<MPNN_NT, 1, false>(h, pb);
+  const int ld = nproj * MPNN_H;
+  for (int u = wave; u < 2 * nproj; u += 4) {
+    const int p = u >> 1, t0 = 4 * (u & 1);
+    f32x4 y[4][1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i][0] = *reinterpret_cast<const f32x4*>(bproj + p * MPNN_H + 16 * (t0 + i) + 4 * g);
+    split_gemm_stream<1, NKK, 4, 3>(Wproj + (size_t)p * WSPLIT + (size_t)t0 * NKK * 2 * 64 + lane, pb, y);
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4*>(PQ + (size_t)nd * ld + p * MPNN_H + 16 * (t0 + i) + 4 * g) = y[i][0];
+    }
+  }
+}
+
 // occupancy MLP: h_V = LN(W2 gelu(w0 * occ + b0) + b2)   (reference :414-421, :461-462)
 __global__ void __launch_bounds__(256)
 k_occupancy_mlp(const float* __restrict__ occ, const float* __restrict__ w0, const float* __restrict__ b0,
@@ -250,7 +344,7 @@ extern "C" int MPNN_API(mpnn_node_update)(const float* hV_in, const float* gsum,
   MPNN_LAUNCH_CHECK();
 }
 
-extern "C" int MPNN_API(mpnn_node_update_subset)(const float* hV_in, const float* gsum, float cnt_const, const float* mask,
+extern "C" int MPNN_API(mpnn_node_update_subset)(const float* hV_in, float* gsum, float cnt_const, const float* mask,
                                        const float* W3_packed, const float* b3, const float* ln1_w,
                                        const float* ln1_b, const float* Win_packed, const float* b_in,
                                        const float* Wout_packed, const float* b_out, const float* ln2_w,
@@ -261,11 +355,10 @@ extern "C" int MPNN_API(mpnn_node_update_subset)(const float* hV_in, const float
                      b_out && ln2_w && ln2_b && hV_out && node_list && n_list > 0 && nproj >= 0,
                  "mpnn_node_update_subset: bad arguments");
   MPNN_CHECK_ARG(nproj == 0 || (Wproj_packed && bproj && PQ), "mpnn_node_update_subset: projections need Wproj, bproj, PQ");
-  hipLaunchKernelGGL(k_node_update, dim3(ceil_div(n_list, 64)), dim3(256), 0, (hipStream_t)stream, hV_in, gsum,
-                     (const float*)nullptr, cnt_const, mask, (const h8*)W3_packed, b3, ln1_w, ln1_b,
-                     (const h8*)Win_packed, b_in, (const h8*)Wout_packed, b_out, ln2_w, ln2_b, 1.0f / scale, 1,
-                     (const h8*)Wproj_packed, bproj, nproj, (const float*)nullptr, 0, 0, (const long long*)nullptr, 0,
-                     n_list, hV_out, PQ, node_list);
+  hipLaunchKernelGGL(k_node_update_level, dim3(ceil_div(n_list, 16)), dim3(256), 0, (hipStream_t)stream, hV_in, gsum,
+                     cnt_const, mask, (const h8*)W3_packed, b3, ln1_w, ln1_b, (const h8*)Win_packed, b_in,
+                     (const h8*)Wout_packed, b_out, ln2_w, ln2_b, 1.0f / scale, (const h8*)Wproj_packed, bproj, nproj,
+                     node_list, n_list, hV_out, PQ);
   MPNN_LAUNCH_CHECK();
 }
 

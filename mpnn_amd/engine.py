@@ -539,7 +539,7 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
         hVs = [enc["hV"].repeat(n_samples, 1)] + [torch.empty(Ns, H, device=dev) for _ in range(n_dec)]
         PA = [PQenc[:, base:base + 2 * H].repeat(n_samples, 1)] + \
              [torch.empty(Ns, 2 * H, device=dev) for _ in range(n_dec - 1)]
-        gsum = torch.empty(Ns, H, device=dev, dtype=torch.float32)
+        gsum = torch.zeros(Ns, H, device=dev, dtype=torch.float32)  # accumulated by atomics, re-zeroed by the node kernel
         import ctypes
         A_rows = (ctypes.c_void_p * n_dec)(*[t.data_ptr() for t in PA])
         A_ld = (ctypes.c_int * n_dec)(*([2 * H] * n_dec))
