@@ -250,6 +250,12 @@ int mpnn_node_wgrad(const float* dY, int ldy, int out_f, const float* X, int ldx
  * neighbours), each level being one launch per kernel over node_list.
  * ------------------------------------------------------------------------------------------------------------ */
 
+/* Dependency levels of a decoding order: level[row][i] = 1 + max level of i's neighbours decoded before i (1 when
+ * none).  order / rank / level are [n_rows][L] (n_rows = n_samples * enc_rows); E_idx32 is the shared [enc_rows*L][16
+ * ceil(K/16)] neighbour list, row r uses structure r % enc_rows. */
+int mpnn_decode_levels(const int64_t* order, const int32_t* rank, const int32_t* E_idx32, int n_rows, int enc_rows,
+                       int L, int K, int32_t* level, void* stream);
+
 /* mpnn_dec_message for the residues in node_list: hE / E_idx32 / edge_mask / PVenc are indexed with
  * (residue % enc_nodes); P, RowA, rank, mask, gsum with the residue id.  One wave per (residue, 16-neighbour tile);
  * the partial sums are ADDED to gsum with atomics: the listed gsum rows must be zero on entry. */

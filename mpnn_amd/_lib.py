@@ -49,6 +49,7 @@ SIGNATURES = {
     "mpnn_edge_features_bwd": [_P] * 4 + [_I] * 3 + [_P] * 4,
     "mpnn_feature_chunks": [_P] * 5 + [_I] * 4 + [_P, _P],
     # autoregressive sampling
+    "mpnn_decode_levels": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "mpnn_dec_message_subset": [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I] + [_P] * 8 + [_I] * 4 + [_P, _P],
     "mpnn_node_update_subset": [_P, _P, _F, _P] + [_P] * 10 + [_F, _P, _P, _I, _P, _I, _P, _P, _P],
     "mpnn_sample_subset": [_P, _P, _P, _P, _I, _P, _I, _F, ctypes.c_uint64, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],

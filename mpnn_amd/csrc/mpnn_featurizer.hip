@@ -443,6 +443,32 @@ __global__ void k_order_rank(const long long* __restrict__ order, int B, int L, 
   if (q >= 0 && q < L) rank[b * L + (int)q] = pos;
 }
 
+// Dependency level of every residue under a decoding order (sampler scheduling): walking the order once,
+//   level[i] = 1 + max{ level[j] : j neighbour of i, rank[j] < rank[i] }.
+// One wavefront per (sample, structure) row keeps the row's levels in LDS; lanes = neighbour slots.
+__global__ void __launch_bounds__(64)
+k_decode_levels(const long long* __restrict__ order, const int* __restrict__ rank, const int* __restrict__ E_idx,
+                int enc_rows, int L, int K, int Kp, int* __restrict__ level) {
+  extern __shared__ int lv[];
+  const int row = blockIdx.x, p = row % enc_rows, lane = threadIdx.x;
+  const long long* ord = order + (size_t)row * L;
+  const int* rk = rank + (size_t)row * L;
+  for (int t = 0; t < L; ++t) {
+    const int i = (int)ord[t];
+    int m = 0;
+    if (lane < K) {
+      const int j = E_idx[((size_t)p * L + i) * Kp + lane];
+      if (rk[j] < t) m = lv[j];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if (lane == 0) {
+      lv[i] = m + 1;
+      level[(size_t)row * L + i] = m + 1;
+    }
+  }
+}
+
 __global__ void k_order_masks(const int* __restrict__ rank, const long long* __restrict__ E_idx64,
                               const float* __restrict__ mask, const float* __restrict__ edge_mask, int B, int L,
                               int K, float* __restrict__ mask_bw, float* __restrict__ mask_fw) {
@@ -702,6 +728,18 @@ extern "C" int mpnn_order_rank(const int64_t* order, int B, int L, int32_t* rank
   MPNN_CHECK_ARG(order && rank && B > 0 && L > 0, "mpnn_order_rank: bad arguments");
   hipLaunchKernelGGL(k_order_rank, dim3(ceil_div((long long)B * L, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const long long*)order, B, L, rank);
+  MPNN_LAUNCH_CHECK();
+}
+#endif
+
+#ifndef MPNN_FAST
+extern "C" int mpnn_decode_levels(const int64_t* order, const int32_t* rank, const int32_t* E_idx32, int n_rows,
+                                  int enc_rows, int L, int K, int32_t* level, void* stream) {
+  MPNN_CHECK_ARG(order && rank && E_idx32 && level, "mpnn_decode_levels: null pointer");
+  MPNN_CHECK_ARG(n_rows > 0 && enc_rows > 0 && n_rows % enc_rows == 0 && L > 0 && L <= 16384 && K >= 1 && K <= 64,
+                 "mpnn_decode_levels: bad sizes (L <= 16384, K <= 64)");
+  hipLaunchKernelGGL(k_decode_levels, dim3(n_rows), dim3(64), (size_t)L * sizeof(int), (hipStream_t)stream,
+                     (const long long*)order, rank, E_idx32, enc_rows, L, K, 16 * ((K + 15) / 16), level);
   MPNN_LAUNCH_CHECK();
 }
 #endif

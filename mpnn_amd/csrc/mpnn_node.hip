@@ -176,7 +176,7 @@ k_node_update_level(const float* __restrict__ hV_in, float* __restrict__ gsum, f
     f32x4 d2[2][1];
 #pragma unroll
     for (int i = 0; i < 2; ++i) d2[i][0] = *reinterpret_cast<const f32x4*>(b3 + 16 * (2 * wave + i) + 4 * g) * cnt_const;
-    split_gemm_stream<1, NKK, 2, 3>(W3 + (size_t)(2 * wave) * NKK * 2 * 64 + lane, xb, d2);
+    split_gemm_stream<1, NKK, 2, 7>(W3 + (size_t)(2 * wave) * NKK * 2 * 64 + lane, xb, d2);
     ex[0][2 * wave][lane] = d2[0][0];
     ex[0][2 * wave + 1][lane] = d2[1][0];
   }
@@ -198,10 +198,10 @@ k_node_update_level(const float* __restrict__ hV_in, float* __restrict__ gsum, f
       hid[t][0] = *reinterpret_cast<const f32x4*>(bin + 128 * wave + 16 * t + 4 * g);
       o[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    split_gemm_stream<1, NKK, MPNN_NT, 3>(Win + (size_t)wave * WSPLIT + lane, xb, hid);
+    split_gemm_stream<1, NKK, MPNN_NT, 8>(Win + (size_t)wave * WSPLIT + lane, xb, hid);
     BFrag hb[NKK][1];
     tile_to_bfrag<MPNN_NT, 1, true>(hid, hb);
-    split_gemm_stream<1, NKK, MPNN_NT, 3>(Wout + (size_t)wave * WSPLIT + lane, hb, o);
+    split_gemm_stream<1, NKK, MPNN_NT, 8>(Wout + (size_t)wave * WSPLIT + lane, hb, o);
   }
   __syncthreads();  // every wave has read the W3 exchange
 #pragma unroll
@@ -227,7 +227,7 @@ k_node_update_level(const float* __restrict__ hV_in, float* __restrict__ gsum, f
     f32x4 y[4][1];
 #pragma unroll
     for (int i = 0; i < 4; ++i) y[i][0] = *reinterpret_cast<const f32x4*>(bproj + p * MPNN_H + 16 * (t0 + i) + 4 * g);
-    split_gemm_stream<1, NKK, 4, 3>(Wproj + (size_t)p * WSPLIT + (size_t)t0 * NKK * 2 * 64 + lane, pb, y);
+    split_gemm_stream<1, NKK, 4, 8>(Wproj + (size_t)p * WSPLIT + (size_t)t0 * NKK * 2 * 64 + lane, pb, y);
     if (live) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -475,15 +475,24 @@ k_sample(const float* __restrict__ hV, const f32x4* __restrict__ Wp, const float
   __builtin_amdgcn_wave_barrier();
   // fold the sequence term of the chosen letter into every decoder layer's A rows (2 floats per lane per row)
   const int nlive = min(16, N - tile * 16);
-  for (int c = 0; c < nlive; ++c) {
-    const int n = node_list[tile * 16 + c], s = pick[wv][c];
-    for (int l = 0; l < rows.n_layers; ++l) {
-      float2* dst = reinterpret_cast<float2*>(rows.A[l] + (size_t)n * rows.ld[l] + rows.off[l]) + lane;
-      const float2 add = *(reinterpret_cast<const float2*>(TS + (size_t)s * ld_ts + l * MPNN_H) + lane);
-      float2 v = *dst;
-      v.x += add.x;
-      v.y += add.y;
-      *dst = v;
+  for (int l = 0; l < rows.n_layers; ++l) {  // 16 independent row updates in flight per layer
+    float2 v[16], add[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c < nlive) {
+        const int n = node_list[tile * 16 + c], s = pick[wv][c];
+        v[c] = *(reinterpret_cast<const float2*>(rows.A[l] + (size_t)n * rows.ld[l] + rows.off[l]) + lane);
+        add[c] = *(reinterpret_cast<const float2*>(TS + (size_t)s * ld_ts + l * MPNN_H) + lane);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c < nlive) {
+        const int n = node_list[tile * 16 + c];
+        v[c].x += add[c].x;
+        v[c].y += add[c].y;
+        *(reinterpret_cast<float2*>(rows.A[l] + (size_t)n * rows.ld[l] + rows.off[l]) + lane) = v[c];
+      }
     }
   }
 }

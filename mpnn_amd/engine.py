@@ -461,24 +461,14 @@ def _encode(model, X, mask, residue_idx, chain_labels, backbone_noise):
     return dict(hE=hE, hV=hV, PQ=PQ, K=K, E_idx64=E_idx64, E_idx32=E_idx32, edge_mask=edge_mask)
 
 
-def decode_levels(rank, E_idx64):
-    """Dependency level of every residue of every sample: 1 + the largest level among the neighbours that are
-    decoded earlier.  Residues of one level only read finished residues, so a level is one batched launch.
-    rank [n_samples, P, L] int64 -> (residue ids sorted by level [n_samples*P*L] int32, residues per level)."""
-    S_, P, L = rank.shape
-    K = E_idx64.shape[-1]
-    nbr = E_idx64.reshape(1, P, L * K).expand(S_, P, L * K)
-    before = torch.gather(rank, 2, nbr).view(S_, P, L, K) < rank.unsqueeze(-1)
-    level = torch.ones(S_, P, L, device=rank.device, dtype=torch.int64)
-    while True:  # monotone relaxation; 8 sweeps between host checks
-        prev = level
-        for _ in range(8):
-            level = 1 + (torch.gather(level, 2, nbr).view(S_, P, L, K) * before).amax(-1)
-        if torch.equal(level, prev):
-            break
-    flat = level.reshape(-1)
-    perm = torch.argsort(flat, stable=True).to(torch.int32)
-    return perm, torch.bincount(flat)[1:].tolist()
+def decode_levels(order, rank, E_idx32, n_rows, enc_rows, L, K):
+    """Dependency level of every residue of every sample (mpnn_decode_levels): residues of one level only read
+    finished residues, so a level is one batched launch.
+    -> (residue ids sorted by level [n_rows*L] int32, residues per level: list of int)."""
+    level = torch.empty(n_rows * L, device=order.device, dtype=torch.int32)
+    call("mpnn_decode_levels", ptr(order), ptr(rank), ptr(E_idx32), n_rows, enc_rows, L, K, ptr(level), stream_ptr())
+    perm = torch.argsort(level, stable=True).to(torch.int32)
+    return perm, torch.bincount(level)[1:].tolist()
 
 
 def sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true=None, n_samples=1, temperature=0.1,
@@ -525,7 +515,7 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
             order = torch.argsort((cm.unsqueeze(0) + 0.0001) * torch.abs(noise), dim=-1)
         rank = torch.zeros(Ns, device=dev, dtype=torch.int32)
         call("mpnn_order_rank", ptr(order), n_samples * B, L, ptr(rank), st)
-        perm, counts = decode_levels(rank.view(n_samples, B, L).to(torch.int64), enc["E_idx64"])
+        perm, counts = decode_levels(order, rank, enc["E_idx32"], n_samples * B, B, L, K)
 
         S_in = _i64(S_true).reshape(1, N).expand(n_samples, N).contiguous() if S_true is not None else \
             torch.zeros(n_samples, N, device=dev, dtype=torch.int64)
