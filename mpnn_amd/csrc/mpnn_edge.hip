@@ -92,17 +92,14 @@ __device__ __forceinline__ void reduce_store(f32x4 (&y)[MPNN_NT][KT], const floa
 // ---------------------------------------------------------------------------
 // SAVE (training forward): the two pre-activations a1 = P + s (Row + W1b e) and a2 = W2 gelu(a1) + b2 are
 // also written out, in the fragment layout of hE, for the backward kernels of mpnn_edge_bwd.hip.
-// SUB (autoregressive sampling): the launch covers the residues listed in node_list (N = list length) of a batch
-// of samples that SHARE one encoder output: hE, E_idx, edge_mask and the encoder rows Bbuf are indexed with
-// (residue % enc_mod), everything else (P, A rows, rank, mask, gsum) with the residue id itself.
-template <int KT, bool DEC, bool SAVE, bool SUB = false>
+template <int KT, bool DEC, bool SAVE>
 __global__ void __launch_bounds__(MPNN_MSG_WAVES * 64)
 k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp, int offP,
           const float* __restrict__ Abuf, int lda, int offA, const float* __restrict__ Bbuf, int ldb, int offB,
           const int* __restrict__ rank, const int* __restrict__ E_idx, const float* __restrict__ mask,
           const float* __restrict__ edge_mask, const h8* __restrict__ W1b, const h8* __restrict__ W2,
           const float* __restrict__ b2, int N, int L, int K, float* __restrict__ gsum, float* __restrict__ cnt,
-          f32x4* __restrict__ sv1, f32x4* __restrict__ sv2, const int* __restrict__ node_list, int enc_mod) {
+          f32x4* __restrict__ sv1, f32x4* __restrict__ sv2) {
   __shared__ h8 lds[2 * WSPLIT];
   lds_fill(lds, W1b, WSPLIT);
   lds_fill(lds + WSPLIT, W2, WSPLIT);
@@ -113,28 +110,24 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
   const int g = lane >> 4, col = lane & 15;
   constexpr int Kp = KT * 16;
   const int stride = gridDim.x * MPNN_MSG_WAVES;
-  int it = blockIdx.x * MPNN_MSG_WAVES + wave;
-  if (it >= N) return;
-  auto nid = [&](int i) { return SUB ? node_list[i] : i; };
+  int node = blockIdx.x * MPNN_MSG_WAVES + wave;
+  if (node >= N) return;
 
   // per-edge scalars of a residue: gathered row, scale s (dec), reduction weight w
   auto setup = [&](int nd, const float* (&row)[KT], float (&s)[KT], float (&w)[KT]) {
     const int b = nd / L;
-    const int sh = SUB ? nd % enc_mod : nd;  // index into the shared encoder-side arrays
     const float mi = mask[nd];
     int ri = 0;
     if (DEC) ri = rank[nd];
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
       const int e = 16 * c + col;
-      const int jl = E_idx[(size_t)sh * Kp + e];
-      const int jn = b * L + jl;
+      const int jn = b * L + E_idx[(size_t)nd * Kp + e];
       float em = 1.0f;
-      if (edge_mask && e < K) em = edge_mask[(size_t)sh * K + e];
+      if (edge_mask && e < K) em = edge_mask[(size_t)nd * K + e];
       if (DEC) {
         const bool before = ri > rank[jn];
-        const int jb = SUB ? (sh / L) * L + jl : jn;
-        row[c] = before ? (Abuf + (size_t)jn * lda + offA + 4 * g) : (Bbuf + (size_t)jb * ldb + offB + 4 * g);
+        row[c] = before ? (Abuf + (size_t)jn * lda + offA + 4 * g) : (Bbuf + (size_t)jn * ldb + offB + 4 * g);
         s[c] = mi * em;
         w[c] = e < K ? 1.0f : 0.0f;
       } else {
@@ -147,16 +140,15 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 
   const float* row[KT];
   float s[KT], w[KT];
-  setup(nid(it), row, s, w);
+  setup(node, row, s, w);
   f32x4 h1[MPNN_NT][KT];
 #pragma unroll
   for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
     for (int c = 0; c < KT; ++c) h1[t][c] = row_tile(row[c], t);
 
-  for (; it < N; it += stride) {
-    const int node = nid(it);
-    const int nxt = nid((it + stride < N) ? it + stride : N - 1);  // tail: harmless re-load of a valid residue
+  for (; node < N; node += stride) {
+    const int nxt = (node + stride < N) ? node + stride : N - 1;  // tail: harmless re-load of a valid residue
     LAUNDER(b2);
     f32x4 p[MPNN_NT];  // P_i: needed only after layer 1
     {
@@ -164,7 +156,7 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t) p[t] = row_tile(Pi, t);
     }
-    layer1_stream<KT>(W1s, hE + (size_t)(SUB ? node % enc_mod : node) * (MPNN_NT * KT * 64) + lane, lane, h1);
+    layer1_stream<KT>(W1s, hE + (size_t)node * (MPNN_NT * KT * 64) + lane, lane, h1);
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
@@ -480,7 +472,8 @@ k_message_tiles(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, in
 // work is one COLUMN TILE (16 neighbours) of one listed residue per wave - three times the parallelism of the
 // residue-per-wave kernels and a third of their latency, which is what bounds a level.  Partial neighbour sums
 // meet in gsum by fp32 atomics (gsum rows must be zero on entry; mpnn_node_update_subset re-zeroes what it reads).
-// Indexing as k_message's SUB mode: encoder-side arrays by (residue % enc_mod).
+// Samples share one encoder output: hE, E_idx, edge_mask and the encoder rows Bbuf are indexed with
+// (residue % enc_mod), everything else (P, A rows, rank, mask, gsum) with the residue id itself.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(MPNN_MSGT_WAVES * 64)
 k_message_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp, int offP,
@@ -574,7 +567,7 @@ extern "C" int MPNN_API(mpnn_enc_message)(const float* hE_frag, const float* PQ,
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, false, false>), grid, block, 0, (hipStream_t)stream,
                                      (const f32x4*)hE_frag, PQ, ldpq, offP, PQ, ldpq, offQ, (const float*)nullptr, 0, 0,
                                      (const int*)nullptr, E_idx32, mask, edge_mask, (const h8*)W1b_packed,
-                                     (const h8*)W2_packed, b2, N, L, K, gsum, cnt, (f32x4*)nullptr, (f32x4*)nullptr, (const int*)nullptr, 0));
+                                     (const h8*)W2_packed, b2, N, L, K, gsum, cnt, (f32x4*)nullptr, (f32x4*)nullptr));
   MPNN_LAUNCH_CHECK();
 }
 
@@ -616,7 +609,7 @@ extern "C" int MPNN_API(mpnn_dec_message)(const float* hE_frag, const float* PQ,
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, true, false>), grid, block, 0, (hipStream_t)stream,
                                      (const f32x4*)hE_frag, PQ, ldpq, offPa, PQ, ldpq, offA, PVenc, ldenc, offEnc, rank,
                                      E_idx32, mask, edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2,
-                                     N, L, K, gsum, (float*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr, (const int*)nullptr, 0));
+                                     N, L, K, gsum, (float*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr));
   MPNN_LAUNCH_CHECK();
 }
 
@@ -637,13 +630,12 @@ extern "C" int mpnn_message_train(int dec, const float* hE_frag, const float* P,
     KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, true, true>), grid, block, 0, (hipStream_t)stream,
                                        (const f32x4*)hE_frag, P, 128, 0, RowA, 128, 0, RowB, 128, 0, rank, E_idx32,
                                        mask, edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2, N, L, K, gsum,
-                                       (float*)nullptr, (f32x4*)a1_frag, (f32x4*)a2_frag, (const int*)nullptr, 0));
+                                       (float*)nullptr, (f32x4*)a1_frag, (f32x4*)a2_frag));
   } else {
     KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, false, true>), grid, block, 0, (hipStream_t)stream,
                                        (const f32x4*)hE_frag, P, 128, 0, RowA, 128, 0, (const float*)nullptr, 0, 0,
                                        (const int*)nullptr, E_idx32, mask, edge_mask, (const h8*)W1b_packed,
-                                       (const h8*)W2_packed, b2, N, L, K, gsum, cnt, (f32x4*)a1_frag, (f32x4*)a2_frag,
-                                       (const int*)nullptr, 0));
+                                       (const h8*)W2_packed, b2, N, L, K, gsum, cnt, (f32x4*)a1_frag, (f32x4*)a2_frag));
   }
   MPNN_LAUNCH_CHECK();
 }
