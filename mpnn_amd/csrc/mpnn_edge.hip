@@ -109,9 +109,10 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, col = lane & 15;
   constexpr int Kp = KT * 16;
-  const int stride = gridDim.x * MPNN_MSG_WAVES;
-  int node = blockIdx.x * MPNN_MSG_WAVES + wave;
-  if (node >= N) return;
+  const ResidueRange rr = residue_range(N, MPNN_MSG_WAVES, wave);
+  const int stride = rr.stride, Nend = rr.end;
+  int node = rr.first;
+  if (node >= Nend) return;
 
   // per-edge scalars of a residue: gathered row, scale s (dec), reduction weight w
   auto setup = [&](int nd, const float* (&row)[KT], float (&s)[KT], float (&w)[KT]) {
@@ -147,8 +148,8 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 #pragma unroll
     for (int c = 0; c < KT; ++c) h1[t][c] = row_tile(row[c], t);
 
-  for (; node < N; node += stride) {
-    const int nxt = (node + stride < N) ? node + stride : N - 1;  // tail: harmless re-load of a valid residue
+  for (; node < Nend; node += stride) {
+    const int nxt = (node + stride < Nend) ? node + stride : Nend - 1;  // tail: harmless re-load of a valid residue
     LAUNDER(b2);
     f32x4 p[MPNN_NT];  // P_i: needed only after layer 1
     {
@@ -166,7 +167,7 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-        for (int c = 0; c < KT; ++c) o[(t * KT + c) * 64] = h1[t][c];
+        for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(h1[t][c], &o[(t * KT + c) * 64]);
     }
     BFrag hb[NKK][KT];
     tile_to_bfrag<MPNN_NT, KT, true>(h1, hb);
@@ -187,7 +188,7 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-        for (int c = 0; c < KT; ++c) o[(t * KT + c) * 64] = y[t][c];
+        for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(y[t][c], &o[(t * KT + c) * 64]);
     }
     // h1 is free: gather the next residue's rows under the GELU + reduction below
 #pragma unroll
@@ -234,9 +235,10 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, col = lane & 15;
   constexpr int Kp = KT * 16;
-  const int stride = gridDim.x * MPNN_UPD_WAVES;
-  int node = blockIdx.x * MPNN_UPD_WAVES + wave;
-  if (node >= N) return;
+  const ResidueRange rr = residue_range(N, MPNN_UPD_WAVES, wave);
+  const int stride = rr.stride, Nend = rr.end;
+  int node = rr.first;
+  if (node >= Nend) return;
 
   auto setup = [&](int nd, const float* (&row)[KT]) {
     const int b = nd / L;
@@ -253,8 +255,8 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #pragma unroll
     for (int c = 0; c < KT; ++c) h2[t][c] = row_tile(row[c], t);
 
-  for (; node < N; node += stride) {
-    const int nxt = (node + stride < N) ? node + stride : N - 1;
+  for (; node < Nend; node += stride) {
+    const int nxt = (node + stride < Nend) ? node + stride : Nend - 1;
     LAUNDER(b12);
     LAUNDER(b13);
     LAUNDER(ln_w);
@@ -284,7 +286,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-        for (int c = 0; c < KT; ++c) sv1[soff + (t * KT + c) * 64] = h1[t][c];
+        for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(h1[t][c], &sv1[soff + (t * KT + c) * 64]);
     }
     BFrag hb[NKK][KT];
     tile_to_bfrag<MPNN_NT, KT, true>(h1, hb);
@@ -302,7 +304,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-        for (int c = 0; c < KT; ++c) sv2[soff + (t * KT + c) * 64] = h2[t][c];
+        for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(h2[t][c], &sv2[soff + (t * KT + c) * 64]);
     }
     // residual e -> layer 3's initial accumulator (loads fly under the GELU + split of h2); the training form
     // adds it after the dropout of the MLP output instead
@@ -350,7 +352,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
           if (drop_thresh)
             h1[t][c] = dropout4(h1[t][c], (unsigned)(soff + (t * KT + c) * 64) * 4u, drop_seed, drop_thresh, inv_keep);
           h1[t][c] += x[(t * KT + c) * 64];
-          svz[soff + (t * KT + c) * 64] = h1[t][c];
+          __builtin_nontemporal_store(h1[t][c], &svz[soff + (t * KT + c) * 64]);
         }
       }
     }
@@ -359,7 +361,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-      for (int c = 0; c < KT; ++c) xo[(t * KT + c) * 64] = h1[t][c];
+      for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(h1[t][c], &xo[(t * KT + c) * 64]);
   }
 }
 
@@ -391,9 +393,9 @@ k_message_tiles(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, in
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, col = lane & 15;
   const int Kp = KT * 16;
-  const int stride = gridDim.x * MPNN_MSGT_WAVES;
+  const ResidueRange rr = residue_range(N, MPNN_MSGT_WAVES, wave);
 
-  for (int node = blockIdx.x * MPNN_MSGT_WAVES + wave; node < N; node += stride) {
+  for (int node = rr.first; node < rr.end; node += rr.stride) {
     const int b = node / L;
     const float mi = mask[node];
     int ri = 0;

@@ -31,7 +31,7 @@ __device__ __forceinline__ void first_layer_grad(f32x4 (&y)[MPNN_NT][KT], float 
       y[t][c] *= gelu_grad4(a[(t * KT + c) * 64]) * unscale;
       ps += y[t][c];
       if (SCALE) y[t][c] *= s[c];
-      *reinterpret_cast<f32x4*>(nat + (size_t)(16 * c + col) * MPNN_H + 16 * t + 4 * g) = y[t][c];
+      __builtin_nontemporal_store(y[t][c], reinterpret_cast<f32x4*>(nat + (size_t)(16 * c + col) * MPNN_H + 16 * t + 4 * g));
     }
     ps.x = column_sum(ps.x); ps.y = column_sum(ps.y); ps.z = column_sum(ps.z); ps.w = column_sum(ps.w);
     if (col == 0) *reinterpret_cast<f32x4*>(dP + 16 * t + 4 * g) = ps;
@@ -89,7 +89,7 @@ k_message_bwd(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, con
 #pragma unroll
         for (int c = 0; c < KT; ++c) {
           d[t][c] = gelu_grad4(a2[off + (t * KT + c) * 64]) * (gs * w[c]);
-          da2[off + (t * KT + c) * 64] = d[t][c];
+          __builtin_nontemporal_store(d[t][c], &da2[off + (t * KT + c) * 64]);
         }
         FENCE();
       }
@@ -110,7 +110,7 @@ k_message_bwd(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, con
       for (int c = 0; c < KT; ++c) {
         f32x4 v = d[t][c] * un;
         if (accumulate) v += dE[off + (t * KT + c) * 64];
-        dE[off + (t * KT + c) * 64] = v;
+        __builtin_nontemporal_store(v, &dE[off + (t * KT + c) * 64]);
       }
   }
   __syncthreads();
@@ -180,7 +180,7 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
 #pragma unroll
       for (int c = 0; c < KT; ++c) {
         x[t][c] *= gelu_grad4(a2[off + (t * KT + c) * 64]) * un;
-        da2_out[off + (t * KT + c) * 64] = x[t][c];
+        __builtin_nontemporal_store(x[t][c], &da2_out[off + (t * KT + c) * 64]);
       }
       FENCE();
     }
@@ -202,7 +202,7 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
 #pragma unroll
       for (int c = 0; c < KT; ++c) {
         const f32x4 res = drop_thresh ? dE[off + (t * KT + c) * 64] : dz_out[off + (t * KT + c) * 64];
-        dE[off + (t * KT + c) * 64] = x[t][c] * un + res;
+        __builtin_nontemporal_store(x[t][c] * un + res, &dE[off + (t * KT + c) * 64]);
       }
   }
   __syncthreads();
@@ -255,7 +255,7 @@ k_features_bwd(const f32x4* __restrict__ dy, const f32x4* __restrict__ E0, const
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-      for (int c = 0; c < KT; ++c) dE0[off + (t * KT + c) * 64] = d[t][c];
+      for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(d[t][c], &dE0[off + (t * KT + c) * 64]);
   }
   __syncthreads();
   if (threadIdx.x < 2 * MPNN_H) unsafeAtomicAdd(dln + threadIdx.x, lnacc[threadIdx.x]);

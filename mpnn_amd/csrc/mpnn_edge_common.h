@@ -38,6 +38,26 @@ __device__ __forceinline__ f32x4 dropout4(f32x4 v, unsigned id0, unsigned seed, 
   return o;
 }
 
+// Residue range of one wave of a persistent edge kernel.  XCD-aware: blocks b and b + 8 share an XCD (observed
+// round-robin dispatch; a speed assumption only), so each of the 8 block classes walks its own contiguous eighth of
+// the residues - the neighbour rows a residue gathers belong to its own protein, which then stays in that XCD's
+// 4 MiB L2 instead of every XCD streaming every protein's rows.
+struct ResidueRange {
+  int first, end, stride;
+};
+__device__ __forceinline__ ResidueRange residue_range(int N, int waves, int wave) {
+  const int G = gridDim.x, b = blockIdx.x;
+#ifndef MPNN_NO_XCD_MAP
+  if (G >= 8 && (G & 7) == 0) {
+    const int chunk = (N + 7) >> 3;
+    const int lo = (b & 7) * chunk;
+    const int hi = lo + chunk < N ? lo + chunk : N;
+    return ResidueRange{lo + (b >> 3) * waves + wave, hi, (G >> 3) * waves};
+  }
+#endif
+  return ResidueRange{b * waves + wave, N, G * waves};
+}
+
 constexpr int NKK = MPNN_NT / 2;       // k-steps (32 features) per 128-wide layer
 constexpr int WSPLIT = 8 * NKK * 2 * 64;  // h8 elements of one packed 128x128 matrix (64 KiB)
 

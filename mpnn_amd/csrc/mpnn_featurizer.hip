@@ -362,7 +362,7 @@ k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, 
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-      for (int c = 0; c < KT; ++c) E0_frag[foff + (t * KT + c) * 64] = acc[t][c];
+      for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(acc[t][c], &E0_frag[foff + (t * KT + c) * 64]);
   }
   // ---- LayerNorm over features (norm_edges)
   tile_layernorm<KT>(acc, ln_w, ln_b, lane);
@@ -370,7 +370,7 @@ k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, 
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-      for (int c = 0; c < KT; ++c) E_frag[foff + (t * KT + c) * 64] = acc[t][c];
+      for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(acc[t][c], &E_frag[foff + (t * KT + c) * 64]);
   }
   if (E_nat) {
 #pragma unroll
@@ -397,7 +397,7 @@ k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, 
 #pragma unroll
   for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
-    for (int c = 0; c < KT; ++c) out[(t * KT + c) * 64 + lane] = acc[t][c];
+    for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(acc[t][c], &out[(t * KT + c) * 64 + lane]);
 }
 
 // ---------------------------------------------------------------------------
