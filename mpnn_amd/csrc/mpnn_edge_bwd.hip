@@ -318,10 +318,11 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
       for (int c = 0; c < 3; ++c) {
         if (c < KT) {
           if (A_NAT)
-            va[tt][c] = *reinterpret_cast<const f32x4*>(A + ((size_t)node * Kp + 16 * c + col) * MPNN_H + 16 * t + 4 * g);
+            va[tt][c] = __builtin_nontemporal_load(
+                reinterpret_cast<const f32x4*>(A + ((size_t)node * Kp + 16 * c + col) * MPNN_H + 16 * t + 4 * g));
           else
-            va[tt][c] = Af[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane];
-          vb[tt][c] = Bf[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane];
+            va[tt][c] = __builtin_nontemporal_load(&Af[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane]);
+          vb[tt][c] = __builtin_nontemporal_load(&Bf[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane]);
         }
       }
     }
