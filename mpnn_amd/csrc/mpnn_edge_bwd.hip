@@ -28,7 +28,7 @@ __device__ __forceinline__ void first_layer_grad(f32x4 (&y)[MPNN_NT][KT], float 
     f32x4 ps = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
-      y[t][c] *= gelu_grad4(a[(t * KT + c) * 64]) * unscale;
+      y[t][c] *= gelu_grad4(__builtin_nontemporal_load(&a[(t * KT + c) * 64])) * unscale;
       ps += y[t][c];
       if (SCALE) y[t][c] *= s[c];
       __builtin_nontemporal_store(y[t][c], reinterpret_cast<f32x4*>(nat + (size_t)(16 * c + col) * MPNN_H + 16 * t + 4 * g));
@@ -88,7 +88,7 @@ k_message_bwd(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, con
         const f32x4 gs = row_tile(dg, t);
 #pragma unroll
         for (int c = 0; c < KT; ++c) {
-          d[t][c] = gelu_grad4(a2[off + (t * KT + c) * 64]) * (gs * w[c]);
+          d[t][c] = gelu_grad4(__builtin_nontemporal_load(&a2[off + (t * KT + c) * 64])) * (gs * w[c]);
           __builtin_nontemporal_store(d[t][c], &da2[off + (t * KT + c) * 64]);
         }
         FENCE();
@@ -154,7 +154,7 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
       for (int c = 0; c < KT; ++c) {
-        x[t][c] = z[off + (t * KT + c) * 64];
+        x[t][c] = __builtin_nontemporal_load(&z[off + (t * KT + c) * 64]);
         d[t][c] = dy[off + (t * KT + c) * 64];
       }
     tile_layernorm_bwd<KT>(x, d, ln_w, lnacc, lane);
@@ -179,7 +179,7 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
     for (int t = 0; t < MPNN_NT; ++t) {
 #pragma unroll
       for (int c = 0; c < KT; ++c) {
-        x[t][c] *= gelu_grad4(a2[off + (t * KT + c) * 64]) * un;
+        x[t][c] *= gelu_grad4(__builtin_nontemporal_load(&a2[off + (t * KT + c) * 64])) * un;
         __builtin_nontemporal_store(x[t][c], &da2_out[off + (t * KT + c) * 64]);
       }
       FENCE();
