@@ -102,6 +102,18 @@ def cpu_baseline(B_cpu, L, K, iters):
                                      f"{trn * 1e3:.0f} ms each"}}
 
 
+def max_over_ranks(x, dev, dist):
+    on_dev = dist.get_backend() == "nccl"
+    t = torch.tensor([x], device=dev if on_dev else "cpu", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def log(msg):
+    if os.environ.get("BENCH_VERBOSE"):
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def train_leg(a, dev, rank, world, dist, barrier, _lib):
     """BASELINE configs[2]: full training step (forward, label-smoothed loss, backward, gradient all-reduce over
     RCCL when world > 1, AdamW) on ~10k-residue batches per rank; reported beside the forward metric."""
@@ -117,7 +129,9 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
     # the reference's training defaults (train.py:199-211): dropout 0.1 (node- and edge-level), backbone noise 0.1 A
     model = ProteinMPNN(k_neighbors=K, augment_eps=0.1, dropout=0.1).train().to(dev)
     if world > 1:
+        log("train: broadcasting parameters")
         distributed.broadcast_parameters(model.parameters())
+        log("train: broadcast done")
     # AdamW(lr, weight_decay=1e-2) as train.py:217; the fused multi-tensor implementation is the same update in one launch
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2, fused=True)
     b = synthetic_batch(B, L, seed=2000 + rank, device=dev)
@@ -129,6 +143,7 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
 
     for _ in range(warm):
         step()
+        log("train: warm-up step done")
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -137,9 +152,7 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(elapsed, dev, dist)
     assert torch.isfinite(loss)
     prof = {}
     _lib.set_profiler(prof)
@@ -199,13 +212,13 @@ def sampling_leg(a, dev, rank, world, dist, barrier):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(elapsed, dev, dist)
         # the job's product: every rank's sequences gathered on all ranks (the path's only collective)
-        gathered = [torch.empty_like(out["S"]) for _ in range(world)] if mine * world == total else None
-        if gathered is not None:
-            dist.all_gather(gathered, out["S"].contiguous())
+        if mine * world == total:
+            mine_S = out["S"].contiguous() if dist.get_backend() == "nccl" else out["S"].cpu()
+            gathered = [torch.empty_like(mine_S) for _ in range(world)]
+            dist.all_gather(gathered, mine_S)
+            assert torch.equal(gathered[rank], mine_S)
     assert int(out["S"].min()) >= 0 and torch.isfinite(out["log_probs"]).all()
     return {"metric": "sampled residues/sec (autoregressive, random order, virtual centre) at L=512,k=48",
             "value": round(total * L * iters / elapsed, 1), "unit": "residues/s", "n_gpus": world, "steps": iters,
@@ -240,12 +253,18 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no ROCm device visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_BACKEND=gloo lets several ranks share one GPU: a rehearsal of the multi-rank code path on a 1-GPU box
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from mpnn_amd import ProteinMPNN, _lib
     from mpnn_amd.synthetic import synthetic_batch
@@ -260,6 +279,7 @@ def main():
         with torch.no_grad():
             return model(*args, fix_order=b["fix_order"])
 
+    log("forward warm-up")
     for _ in range(a.warmup):
         step()
 
@@ -270,15 +290,15 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
+    log("forward timed region")
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
     barrier()
+    log("forward done")
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(elapsed, dev, dist)
     assert torch.isfinite(out).all()
 
     # ---- per-kernel device time (HIP events on the launch stream), separate from the timed region
@@ -344,14 +364,17 @@ def main():
         f16[tag] = {"residues_per_s_fp32": round(res["fp32"][0], 1), "residues_per_s_f16": round(res["f16"][0], 1),
                     "max_abs_dlogp": round(float((res["f16"][1] - res["fp32"][1]).abs().max()), 5)}
 
+    log("f16 leg done")
     train = None
     if a.train_batch > 0:
         train = train_leg(a, dev, rank, world, dist, barrier, _lib)
 
+    log("train leg done")
     sampling = None
     if a.samples > 0:
         sampling = sampling_leg(a, dev, rank, world, dist, barrier)
 
+    log("sampling leg done")
     if rank == 0:
         total_res = B * L * world * a.steps
         value = total_res / elapsed

@@ -41,7 +41,12 @@ def allreduce_gradients(params, world: int, group=None):
     if world <= 1 or not params:
         return
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if flat.is_cuda and dist.get_backend(group) == "gloo":  # CPU rehearsal backend: stage through host memory
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.div_(world)
     off = 0
     for p in params:
@@ -60,7 +65,12 @@ def broadcast_parameters(params, src: int = 0, group=None):
     if not dist.is_initialized() or not params:
         return
     flat = torch.cat([p.data.reshape(-1) for p in params])
-    dist.broadcast(flat, src=src, group=group)
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        host = flat.cpu()
+        dist.broadcast(host, src=src, group=group)
+        flat.copy_(host)
+    else:
+        dist.broadcast(flat, src=src, group=group)
     off = 0
     for p in params:
         n = p.numel()
