@@ -158,14 +158,30 @@ struct BFrag {
   h8 hi, lo;
 };
 
+// hi by v_cvt_pkrtz_f16_f32 (two conversions and the packing in one instruction; truncation instead of rounding is
+// immaterial because lo = f16(x - hi) picks up the exact residual: |x - hi - lo| <= 2^-21 |x|)
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair(const f32x4 a, const f32x4 b, BFrag& o) {
   const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const _Float16 h = (_Float16)v[j];
-    o.hi[j] = h;
+  for (int j = 0; j < 8; j += 2) {
+#ifdef MPNN_SPLIT_RTN
+    const _Float16 h0 = (_Float16)v[j], h1 = (_Float16)v[j + 1];
+#else
+    const fp16x2_t hp = __builtin_amdgcn_cvt_pkrtz(v[j], v[j + 1]);
+    const _Float16 h0 = (_Float16)hp[0], h1 = (_Float16)hp[1];
+#endif
+    o.hi[j] = h0;
+    o.hi[j + 1] = h1;
 #ifndef MPNN_FAST
-    o.lo[j] = (_Float16)(v[j] - (float)h);
+#ifdef MPNN_SPLIT_RTN
+    o.lo[j] = (_Float16)(v[j] - (float)h0);
+    o.lo[j + 1] = (_Float16)(v[j + 1] - (float)h1);
+#else
+    const fp16x2_t lp = __builtin_amdgcn_cvt_pkrtz(v[j] - (float)h0, v[j + 1] - (float)h1);
+    o.lo[j] = (_Float16)lp[0];
+    o.lo[j + 1] = (_Float16)lp[1];
+#endif
 #endif
   }
 }
