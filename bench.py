@@ -39,6 +39,24 @@ FLOP_F16_ISSUED = {
     "mpnn_dec_message": 3 * 2 * 48 * 2 * 128 * 128,
     "mpnn_edge_features": 3 * 2 * 48 * (416 * 128 + 128 * 128),
 }
+
+
+def algorithmic_bytes(name, K, Kp):
+    """Minimum HBM bytes per residue and launch: every tensor the launch must read or write
+    counted once; gathered neighbour rows counted at full size although most of them hit in L2."""
+    F = 512 * Kp  # one residue's hE block (fragment layout, padded to 16-neighbour tiles)
+    return {
+        "mpnn_backbone_atoms": 48 + 112,
+        "mpnn_knn_topk": 16 + 12 * K,                         # Ca + mask in; E_idx (i64 API + i32 internal) out
+        "mpnn_edge_features": 112 + K * (112 + 4) + F,        # own + gathered atom rows, indices; hE out
+        "mpnn_enc_message": F + 512 * K + 4 * K + 512 + 516,  # hE, gathered Q rows, indices, P row; gsum + cnt out
+        "mpnn_dec_message": F + 512 * K + 8 * K + 512 + 512,  # hE, one gathered row per edge, indices + ranks; gsum out
+        "mpnn_enc_edge_update": 2 * F + 512 * K + 4 * K + 512,  # hE in and out, gathered Q' rows, P' row
+        "mpnn_node_update": 6 * 512,                          # h_V, gsum in; h_V and up to three projections out
+    }.get(name)
+
+
+PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 PEAK_F32_MFMA_TFLOPS = 157.3   # for reference: the f32-input MFMA / f32 vector peak
 
@@ -128,7 +146,7 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
     torch.manual_seed(1234)
     # the reference's training defaults (train.py:199-211): dropout 0.1 (node- and edge-level), backbone noise 0.1 A
     model = ProteinMPNN(k_neighbors=K, augment_eps=0.1, dropout=0.1).train().to(dev)
-    if world > 1:
+    if dist is not None:
         log("train: broadcasting parameters")
         distributed.broadcast_parameters(model.parameters())
         log("train: broadcast done")
@@ -243,6 +261,12 @@ def main():
                     help="sequences drawn per structure in the sampling leg (BASELINE configs[4]); 0 = skip")
     a = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON: anything a library prints there (RCCL's start-up banner does) goes to
+    # stderr instead, by pointing fd 1 at stderr until the line is written
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -259,7 +283,8 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1 (under torch.distributed.run with one rank) sends the one-rank run through the RCCL code path too
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
@@ -314,6 +339,20 @@ def main():
         ms = [e0.elapsed_time(e1) for e0, e1 in evs]
         per_kernel[name] = {"launches_per_step": len(ms) / psteps, "avg_ms": sum(ms) / len(ms),
                             "ms_per_step": sum(ms) / psteps}
+    # every forward kernel against both roofs: algorithmic HBM bytes and issued f16 MFMA FLOPs over its launch time
+    kernel_rooflines = {}
+    for name, v in sorted(per_kernel.items()):
+        sec = v["avg_ms"] * 1e-3
+        row = {"launches_per_step": round(v["launches_per_step"], 2), "avg_launch_ms": round(v["avg_ms"], 4)}
+        nbytes = algorithmic_bytes(name, min(K, L), 16 * ((min(K, L) + 15) // 16))
+        if nbytes:
+            row["hbm_GBps"] = round(nbytes * B * L / sec / 1e9, 1)
+            row["hbm_frac"] = round(nbytes * B * L / sec / 1e9 / PEAK_HBM_GBPS, 4)
+        if name in FLOP_F16_ISSUED:
+            tf = FLOP_F16_ISSUED[name] * (16 * ((min(K, L) + 15) // 16) / 48) * B * L / sec / 1e12  # tables are per K = 48
+            row["mfma_f16_TFLOPs"] = round(tf, 1)
+            row["mfma_frac"] = round(tf / PEAK_F16_MFMA_TFLOPS, 4)
+        kernel_rooflines[name] = row
     dominant = max(per_kernel, key=lambda n: per_kernel[n]["ms_per_step"])
     dk = per_kernel[dominant]
     roofline = None
@@ -389,6 +428,7 @@ def main():
             "whole_forward_tflops_as_written": round(FLOP_FWD_PER_RES * value / 1e12, 2),
             "roofline": roofline,
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(per_kernel.items())},
+            "kernel_rooflines": kernel_rooflines,
         }
         line["forward_f16_products"] = dict(f16, note="per-rank; one f16 MFMA product per fp32 product instead of three; "
                                             "fp32 accumulate / GELU / LayerNorm; tolerance in include/mpnn_hip.h")
@@ -398,7 +438,8 @@ def main():
             line["sampling"] = sampling
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(2, L, K, iters=3)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

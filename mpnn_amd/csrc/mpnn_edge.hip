@@ -311,9 +311,16 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
+#ifdef MPNN_ABL_NORES
+      for (int c = 0; c < KT; ++c) h1[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
       for (int c = 0; c < KT; ++c) h1[t][c] = SAVE ? f32x4{0.f, 0.f, 0.f, 0.f} : x[(t * KT + c) * 64];
+#endif
     tile_to_bfrag<MPNN_NT, KT, true>(h2, hb);
     // ---- layer 3; W13 fragments (hi, lo) from L2, D steps ahead.  step q = kk * 8 + to
+#ifdef MPNN_ABL_W3LDS  // timing-only ablation build: never shipped
+    split_gemm<KT, NKK, 0, MPNN_NT>(W2s, lane, hb, h1);
+#else
     {
       constexpr int D = 3;
       h8 ah[D + 1], al[D + 1];
@@ -337,6 +344,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
         FENCE();
       }
     }
+#endif
     // next residue's Q' rows -> h2 (carried to the next iteration), under LayerNorm + store
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
@@ -356,8 +364,13 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
         }
       }
     }
+#ifndef MPNN_ABL_NOLN
     tile_layernorm<KT>(h1, ln_w, ln_b, lane);
+#endif
     f32x4* xo = SAVE ? hE_out + soff : x;
+#ifdef MPNN_ABL_NOSTORE
+    if (h1[0][0].x == 1234.5f)
+#endif
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll

@@ -38,7 +38,9 @@ def shard_range(n_items: int, rank: int, world: int):
 def allreduce_gradients(params, world: int, group=None):
     """Average `.grad` over ranks with a single flat all-reduce (parameters without a grad count as zeros)."""
     params = [p for p in params if p.requires_grad]
-    if world <= 1 or not params:
+    # MPNN_FORCE_ALLREDUCE=1: a one-rank process group still takes the collective path (rehearsal of the RCCL path on a 1-GPU box)
+    forced = os.environ.get("MPNN_FORCE_ALLREDUCE") == "1" and dist.is_initialized()
+    if (world <= 1 and not forced) or not params:
         return
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     if flat.is_cuda and dist.get_backend(group) == "gloo":  # CPU rehearsal backend: stage through host memory

@@ -555,7 +555,6 @@ def train_step(model, optimizer, batch, world_size=1, fix_order=None, fix_backbo
     mask_for_loss = mask * chain_M
     _, loss = loss_smoothed(S, log_probs, mask_for_loss)
     loss.backward()
-    if world_size > 1:
-        distributed.allreduce_gradients(model.parameters(), world_size)
+    distributed.allreduce_gradients(model.parameters(), world_size)  # no-op for a single rank
     optimizer.step()
     return loss.detach(), log_probs.detach()

@@ -37,7 +37,8 @@ def _worker(rank, world, port, out):
     gw = [torch.empty_like(w0) for _ in range(world)]
     dist.all_gather(gw, w0)
     if rank == 0:
-        out.put((flat.clone(), [g.clone() for g in gathered], [g.clone() for g in gw]))
+        # plain lists: tensors would travel as shared-memory handles that die with this process
+        out.put((flat.tolist(), [g.tolist() for g in gathered], [g.tolist() for g in gw]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,6 +51,9 @@ def test_gradient_allreduce_and_broadcast_two_ranks():
     for p in procs:
         p.start()
     flat, gathered, weights = q.get(timeout=120)
+    flat = torch.tensor(flat)
+    gathered = [torch.tensor(g) for g in gathered]
+    weights = [torch.tensor(w) for w in weights]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
