@@ -38,6 +38,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MPNN_API(name) name
 #endif
 
+// Kernels of the sources that are compiled twice (fp32-class and -DMPNN_FAST) sit in a precision-named inline namespace
+// inside the anonymous one, so profiler output tells the two builds of a kernel apart.
+#ifdef MPNN_FAST
+#define MPNN_KERNELS_BEGIN namespace { inline namespace f16 {
+#else
+#define MPNN_KERNELS_BEGIN namespace { inline namespace fp32 {
+#endif
+#define MPNN_KERNELS_END } }
+
 namespace {
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {

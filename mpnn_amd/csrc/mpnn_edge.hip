@@ -22,7 +22,7 @@
 // Two waves per SIMD (8-wave workgroups) let one wave's GELU / reductions run under the other's MFMAs.
 #include "mpnn_edge_common.h"
 
-namespace {
+MPNN_KERNELS_BEGIN
 
 #ifndef MPNN_MSG_WAVES
 #define MPNN_MSG_WAVES 8
@@ -557,7 +557,7 @@ k_message_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, in
   }
 }
 
-}  // namespace
+MPNN_KERNELS_END
 
 // ===========================================================================
 // C ABI launchers

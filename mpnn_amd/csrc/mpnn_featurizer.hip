@@ -3,7 +3,7 @@
 // round every operation exactly like the reference's separate ATen ops do.
 #include "mpnn_common.h"
 
-namespace {
+MPNN_KERNELS_BEGIN
 
 // ---------------------------------------------------------------------------
 // backbone atoms: X [N,4,3] (+noise) -> atoms [N][6][4] = N, CA, C, O, CB, V (xyz + pad)
@@ -487,7 +487,7 @@ __global__ void k_order_masks(const int* __restrict__ rank, const long long* __r
   mask_fw[idx] = fw;
 }
 
-}  // namespace
+MPNN_KERNELS_END
 
 // ===========================================================================
 // C ABI launchers (declared in include/mpnn_hip.h)
@@ -625,7 +625,7 @@ extern "C" int mpnn_edge_features_train(const float* atoms, const int32_t* E_idx
 #endif
 
 #ifndef MPNN_FAST
-namespace {
+MPNN_KERNELS_BEGIN
 // ---------------------------------------------------------------------------
 // Training: the featurizer's raw inputs, materialised once per backward pass in the fragment layout so that the
 // generic per-edge weight-gradient kernel (mpnn_edge_wgrad) can contract them with dE0:
@@ -679,7 +679,7 @@ k_feature_chunks(const float* __restrict__ atoms, const int* __restrict__ E_idx,
   }
 }
 
-}  // namespace
+MPNN_KERNELS_END
 #endif
 #ifndef MPNN_FAST
 extern "C" int mpnn_feature_chunks(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,

@@ -3,7 +3,7 @@
 // (reference: src/mpnn/models/model_utils.py :81-88, :127-137, :151-155, :414-421, :527-528).
 #include "mpnn_common.h"
 
-namespace {
+MPNN_KERNELS_BEGIN
 
 // ---------------------------------------------------------------------------
 // node update + projections: one wavefront per 16 nodes, 4 waves (64 nodes) per workgroup, split-f16 MFMA.
@@ -313,7 +313,7 @@ k_logits(const float* __restrict__ hV, const f32x4* __restrict__ Wp, const float
   }
 }
 
-}  // namespace
+MPNN_KERNELS_END
 
 // ===========================================================================
 // C ABI launchers
@@ -363,7 +363,7 @@ extern "C" int MPNN_API(mpnn_node_update_subset)(const float* hV_in, float* gsum
 }
 
 #ifndef MPNN_FAST
-namespace {
+MPNN_KERNELS_BEGIN
 // ---------------------------------------------------------------------------
 // Sampling head for a listed subset of residues (one wave = 16 residues):
 //   logits = W_out h + b;  log_probs = log_softmax(logits)  (the model's distribution, what a teacher-forced
@@ -497,7 +497,7 @@ k_sample(const float* __restrict__ hV, const f32x4* __restrict__ Wp, const float
   }
 }
 
-}  // namespace
+MPNN_KERNELS_END
 #endif
 #ifndef MPNN_FAST
 extern "C" int mpnn_sample_subset(const float* hV, const float* Wout_packed, const float* bias, const float* logit_bias,
