@@ -29,6 +29,13 @@ extern "C" {
 #endif
 
 int mpnn_version(void);
+
+/* Recommended workspace size in bytes for the entry points that take one ("mpnn_edge_wgrad": n_rows = residues;
+ * "mpnn_node_wgrad" / "mpnn_node_wgrad_batch": n_rows = rows of the operands, n_blocks = number of 128 x 128 blocks of
+ * all outputs of the call).  Smaller workspaces are accepted down to one partial (16512 floats) and cost parallelism.
+ * 0 for the entry points that need none, -1 for an unknown name.  Host-only: touches no device.
+ * (SURVEY section 8b lists this query in the build-defined ABI; nothing in the reference corresponds to it.) */
+long long mpnn_workspace_bytes(const char* entry, int n_rows, int n_blocks);
 const char* mpnn_last_error(void);
 
 /* nn.Linear weight W[out_f, ld] columns [col0, col0+in_f) -> packed[ceil(out/16)][ceil(in/16)][64][4],

@@ -100,6 +100,8 @@ def load() -> ctypes.CDLL:
         fn.restype = _I
     lib.mpnn_version.restype = _I
     lib.mpnn_version.argtypes = []
+    lib.mpnn_workspace_bytes.restype = ctypes.c_longlong
+    lib.mpnn_workspace_bytes.argtypes = [ctypes.c_char_p, _I, _I]
     lib.mpnn_last_error.restype = ctypes.c_char_p
     lib.mpnn_last_error.argtypes = []
     _lib = lib

@@ -12,3 +12,22 @@ extern "C" void mpnn_set_error(const char* msg) {
 extern "C" const char* mpnn_last_error(void) { return g_err; }
 
 extern "C" int mpnn_version(void) { return 1; }
+
+// Workspace query (include/mpnn_hip.h).  16512 floats = one 128 x 128 partial + 128 bias sums.
+extern "C" long long mpnn_workspace_bytes(const char* entry, int n_rows, int n_blocks) {
+  const long long part = 16512LL * (long long)sizeof(float);
+  if (!entry || n_rows < 0 || n_blocks < 0) return -1;
+  if (!strcmp(entry, "mpnn_edge_wgrad")) {  // one partial per workgroup, at most 2 per CU of the largest part (256 CUs)
+    const long long wg = n_rows < 512 ? (n_rows > 0 ? n_rows : 1) : 512;
+    return wg * part;
+  }
+  if (!strcmp(entry, "mpnn_node_wgrad") || !strcmp(entry, "mpnn_node_wgrad_batch")) {
+    // one partial per 128 x 128 output block and row chunk; chunks of >= 32 rows, at most 256 of them
+    long long chunks = (n_rows + 31) / 32;
+    if (chunks > 256) chunks = 256;
+    if (chunks < 1) chunks = 1;
+    return chunks * (n_blocks > 0 ? n_blocks : 1) * part;
+  }
+  if (!strncmp(entry, "mpnn_", 5)) return 0;  // every other entry point works in the caller's inputs and outputs only
+  return -1;
+}

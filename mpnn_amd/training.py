@@ -21,6 +21,7 @@ import torch
 import torch.nn.functional as F
 
 from . import engine
+from . import _lib
 from ._lib import call, ptr, stream_ptr
 
 H = 128
@@ -140,7 +141,9 @@ def _workspace(dev):
     """Per-device scratch for the weight-gradient kernels' partial sums (calls on one stream reuse it in order)."""
     ws = _WS.get(dev)
     if ws is None:
-        ws = _WS[dev] = torch.empty(512 * 16512, device=dev, dtype=torch.float32)
+        # the largest request of any call in a step: the edge weight gradient at full width (mpnn_workspace_bytes)
+        nbytes = _lib.load().mpnn_workspace_bytes(b"mpnn_edge_wgrad", 1 << 30, 1)
+        ws = _WS[dev] = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
     return ws
 
 

@@ -39,6 +39,20 @@ def test_library_exports_every_declared_symbol():
     assert lib.mpnn_version() >= 1
 
 
+def test_workspace_query():
+    from mpnn_amd import _lib
+
+    lib = _lib.load()
+    part = 16512 * 4
+    assert lib.mpnn_workspace_bytes(b"mpnn_edge_wgrad", 16384, 1) == 512 * part
+    assert lib.mpnn_workspace_bytes(b"mpnn_edge_wgrad", 100, 1) == 100 * part
+    assert lib.mpnn_workspace_bytes(b"mpnn_node_wgrad", 10240, 4) == 256 * 4 * part
+    assert lib.mpnn_workspace_bytes(b"mpnn_node_wgrad_batch", 64, 11) == 2 * 11 * part
+    assert lib.mpnn_workspace_bytes(b"mpnn_enc_message", 16384, 0) == 0
+    assert lib.mpnn_workspace_bytes(b"no_such_entry", 1, 1) == -1
+    assert lib.mpnn_workspace_bytes(None, 1, 1) == -1
+
+
 def test_argument_rejection_without_gpu():
     """Launchers validate before touching the device: bad arguments return -1 with a message."""
     from mpnn_amd import _lib
