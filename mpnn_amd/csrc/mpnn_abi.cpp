@@ -17,8 +17,8 @@ extern "C" int mpnn_version(void) { return 1; }
 extern "C" long long mpnn_workspace_bytes(const char* entry, int n_rows, int n_blocks) {
   const long long part = 16512LL * (long long)sizeof(float);
   if (!entry || n_rows < 0 || n_blocks < 0) return -1;
-  if (!strcmp(entry, "mpnn_edge_wgrad")) {  // one partial per workgroup, at most 2 per CU of the largest part (256 CUs)
-    const long long wg = n_rows < 512 ? (n_rows > 0 ? n_rows : 1) : 512;
+  if (!strcmp(entry, "mpnn_edge_wgrad")) {  // one partial per workgroup, at most 3 per CU of the largest part (256 CUs)
+    const long long wg = n_rows < 768 ? (n_rows > 0 ? n_rows : 1) : 768;
     return wg * part;
   }
   if (!strcmp(entry, "mpnn_node_wgrad") || !strcmp(entry, "mpnn_node_wgrad_batch")) {

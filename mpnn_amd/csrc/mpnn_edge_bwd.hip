@@ -401,6 +401,10 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
     }
 }
 
+#ifndef MPNN_WGRAD_WG_PER_CU
+#define MPNN_WGRAD_WG_PER_CU 3
+#endif
+
 // dW[i] += sum_w part[w][i]  (slice blockIdx.y of the partials; slices meet with one atomic per element)
 __global__ void __launch_bounds__(256)
 k_wgrad_reduce(const float* __restrict__ part, int nparts, float* __restrict__ dW, float* __restrict__ db) {
@@ -533,9 +537,10 @@ extern "C" int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
-  int nwg = n_nodes < 2 * cus ? n_nodes : 2 * cus;
+  // three workgroups per CU (LDS 52 KiB, 166 registers each): the launch is bound by how many operand bytes are in flight
+  int nwg = n_nodes < MPNN_WGRAD_WG_PER_CU * cus ? n_nodes : MPNN_WGRAD_WG_PER_CU * cus;
   if (nwg > workspace_floats / WG_PART) nwg = workspace_floats / WG_PART;
-  MPNN_CHECK_ARG(nwg >= 1, "mpnn_edge_wgrad: workspace holds no partial (needs >= 16512 floats, ideally 512 x 16512)");
+  MPNN_CHECK_ARG(nwg >= 1, "mpnn_edge_wgrad: workspace holds no partial (needs >= 16512 floats, ideally 768 x 16512: mpnn_workspace_bytes)");
   dim3 grid(nwg), block(256);
   hipStream_t st = (hipStream_t)stream;
   const f32x4* Bf = (const f32x4*)B_frag;

@@ -44,7 +44,7 @@ def test_workspace_query():
 
     lib = _lib.load()
     part = 16512 * 4
-    assert lib.mpnn_workspace_bytes(b"mpnn_edge_wgrad", 16384, 1) == 512 * part
+    assert lib.mpnn_workspace_bytes(b"mpnn_edge_wgrad", 16384, 1) == 768 * part
     assert lib.mpnn_workspace_bytes(b"mpnn_edge_wgrad", 100, 1) == 100 * part
     assert lib.mpnn_workspace_bytes(b"mpnn_node_wgrad", 10240, 4) == 256 * 4 * part
     assert lib.mpnn_workspace_bytes(b"mpnn_node_wgrad_batch", 64, 11) == 2 * 11 * part
