@@ -132,6 +132,15 @@ def log(msg):
         print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
 
 
+def quiesce_gc():
+    """Before a timed region: one full cyclic-GC pass of CPython scans every object torch and the earlier legs left
+    behind (~40 ms here, during which nothing is enqueued and the GPU drains); whether one falls into a 70 ms timed
+    region depends on the allocation count at that moment.  Collect now and move the survivors out of the collector's
+    sight, so the timed steps only ever trigger young-generation passes."""
+    gc.collect()
+    gc.freeze()
+
+
 def train_leg(a, dev, rank, world, dist, barrier, _lib):
     """BASELINE configs[2]: full training step (forward, label-smoothed loss, backward, gradient all-reduce over
     RCCL when world > 1, AdamW) on ~10k-residue batches per rank; reported beside the forward metric."""
@@ -141,8 +150,7 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
     B, L, K = a.train_batch, a.length, a.k
     # objects of the earlier legs (models, thousands of timing events) would be re-scanned by every cyclic-GC pass the
     # autograd graph triggers (measured: 24 instead of 17 ms per step): collect once, then exclude them from scanning
-    gc.collect()
-    gc.freeze()
+    quiesce_gc()
     torch.manual_seed(1234)
     # the reference's training defaults (train.py:199-211): dropout 0.1 (node- and edge-level), backbone noise 0.1 A
     model = ProteinMPNN(k_neighbors=K, augment_eps=0.1, dropout=0.1).train().to(dev)
@@ -162,6 +170,7 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
     for _ in range(warm):
         step()
         log("train: warm-up step done")
+    quiesce_gc()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -223,6 +232,7 @@ def sampling_leg(a, dev, rank, world, dist, barrier):
         return model.sample(*args, n_samples=max(mine, 1), temperature=0.1, seed=100 * i + rank)
 
     out = step(0)
+    quiesce_gc()
     barrier()
     t0 = time.perf_counter()
     for i in range(iters):
@@ -314,14 +324,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    quiesce_gc()
     barrier()
     log("forward timed region")
+    prof_host = None
+    if os.environ.get("BENCH_CPROFILE"):  # debugging aid: where the host time of the timed region goes
+        import cProfile
+        prof_host = cProfile.Profile()
+        prof_host.enable()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
+    enqueue = time.perf_counter() - t0
+    if prof_host is not None:
+        prof_host.disable()
+        import pstats
+        pstats.Stats(prof_host, stream=sys.stderr).sort_stats("tottime").print_stats(14)
     barrier()
-    log("forward done")
     elapsed = time.perf_counter() - t0
+    log(f"forward done: {elapsed / a.steps * 1e3:.3f} ms per step, host enqueue {enqueue / a.steps * 1e3:.3f} ms")
     if dist is not None:
         elapsed = max_over_ranks(elapsed, dev, dist)
     assert torch.isfinite(out).all()
@@ -384,6 +405,7 @@ def main():
 
     # ---- secondary: reduced-precision forward (one f16 product per fp32 product), same workload and the L=4096 shape
     f16 = {}
+    quiesce_gc()
     for tag, (Bq, Lq) in ({} if a.no_f16_leg else {"B%dxL%d" % (B, L): (B, L), "B4xL4096": (4, 4096)}).items():
         bq = b if (Bq, Lq) == (B, L) else synthetic_batch(Bq, Lq, seed=4000 + rank, device=dev)
         aq = (bq["X"], bq["S"], bq["mask"], bq["chain_M"], bq["residue_idx"], bq["chain_encoding_all"])
@@ -404,6 +426,31 @@ def main():
                     "max_abs_dlogp": round(float((res["f16"][1] - res["fp32"][1]).abs().max()), 5)}
 
     log("f16 leg done")
+    # ---- secondary: many sequences on ONE structure (the EnergyMPNN workload, energy_mpnn.py:42-62): the same B x L rows,
+    # structure side passed once, against the same call with the structure repeated B times as the reference does
+    shared = None
+    if not a.no_f16_leg and B > 1:
+        one = synthetic_batch(1, L, seed=5000 + rank, device=dev)
+        side1 = (one["X"], one["mask"], one["residue_idx"], one["chain_encoding_all"])
+        sideB = tuple(t.repeat(B, *([1] * (t.dim() - 1))) for t in side1)
+        cmB = one["chain_M"].repeat(B, 1)
+        rates = {}
+        for tag, sd in (("shared", side1), ("repeated", sideB)):
+            with torch.no_grad():
+                for _ in range(2):
+                    o = model(sd[0], b["S"], sd[1], cmB, sd[2], sd[3], fix_order=b["fix_order"])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    o = model(sd[0], b["S"], sd[1], cmB, sd[2], sd[3], fix_order=b["fix_order"])
+                torch.cuda.synchronize()
+            rates[tag] = (B * L * 5 / (time.perf_counter() - t1), o)
+        shared = {"workload": f"{B} sequences x L={L} on one structure, k={K}, teacher-forced forward (per rank)",
+                  "residues_per_s_shared": round(rates["shared"][0], 1),
+                  "residues_per_s_repeated": round(rates["repeated"][0], 1),
+                  "bit_identical": bool(torch.equal(rates["shared"][1], rates["repeated"][1])),
+                  "note": "featurizer + encoder once per distinct structure (mpnn_dec_message_shared); SURVEY 8f N2"}
+    log("shared-structure leg done")
     train = None
     if a.train_batch > 0:
         train = train_leg(a, dev, rank, world, dist, barrier, _lib)
@@ -420,7 +467,8 @@ def main():
         line = {
             "metric": "residues/sec (enc+dec fwd) at L=512,k=48",
             "value": round(value, 1), "unit": "residues/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "host_enqueue_ms_per_step": round(enqueue / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (products as 3x f16-split MFMA, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: synthetic backbones, batch {B} x L={L}, k={K}, hidden 128, "
                                    "3 enc + 3 dec layers, fp32 forward + teacher-forced decoder",
@@ -429,6 +477,7 @@ def main():
             "roofline": roofline,
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(per_kernel.items())},
             "kernel_rooflines": kernel_rooflines,
+            "shared_structure": shared,
         }
         line["forward_f16_products"] = dict(f16, note="per-rank; one f16 MFMA product per fp32 product instead of three; "
                                             "fp32 accumulate / GELU / LayerNorm; tolerance in include/mpnn_hip.h")

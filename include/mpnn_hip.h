@@ -112,6 +112,15 @@ int mpnn_dec_message(const float* hE_frag, const float* PQ, int ldpq, int offPa,
                      const float* edge_mask, const float* W1b_packed, const float* W2_packed, const float* b2, int B,
                      int L, int K, float* gsum, void* stream);
 
+/* mpnn_dec_message for B rows that decode only n_struct distinct structures (row r: structure r % n_struct; K <= 48):
+ * hE_frag, E_idx32, edge_mask and the encoder rows PVenc hold n_struct * L residues and are shared by the rows;
+ * PQ (Pa | A), rank, mask and gsum hold B * L.  The reference repeats the structure B times and runs featurizer and
+ * encoder on every copy (energy_mpnn.py:42-62); SURVEY section 8f N2. */
+int mpnn_dec_message_shared(const float* hE_frag, const float* PQ, int ldpq, int offPa, int offA, const float* PVenc,
+                            int ldenc, int offEnc, const int32_t* rank, const int32_t* E_idx32, const float* mask,
+                            const float* edge_mask, const float* W1b_packed, const float* W2_packed, const float* b2,
+                            int B, int n_struct, int L, int K, float* gsum, void* stream);
+
 /* Node update shared by EncLayer / DecLayer (:81-88, :127-137, FFN :151-155) followed by the next kernels'
  * node projections:  dh = (W3 gsum + cnt b3) / scale;  x = LN1(h + dh);  h' = mask LN2(x + FFN(x));
  *   PQ[n, 128 p : 128 (p+1)] = Wproj_p h' + bproj_p,  p < nproj;
@@ -317,6 +326,10 @@ int mpnn_dec_message_f16(const float* hE_frag, const float* PQ, int ldpq, int of
                      int ldenc, int offEnc, const int32_t* rank, const int32_t* E_idx32, const float* mask,
                      const float* edge_mask, const float* W1b_packed, const float* W2_packed, const float* b2, int B,
                      int L, int K, float* gsum, void* stream);
+int mpnn_dec_message_shared_f16(const float* hE_frag, const float* PQ, int ldpq, int offPa, int offA, const float* PVenc,
+                                int ldenc, int offEnc, const int32_t* rank, const int32_t* E_idx32, const float* mask,
+                                const float* edge_mask, const float* W1b_packed, const float* W2_packed, const float* b2,
+                                int B, int n_struct, int L, int K, float* gsum, void* stream);
 
 int mpnn_node_update_f16(const float* hV_in, const float* gsum, const float* cnt, float cnt_const, const float* mask,
                      const float* W3_packed, const float* b3, const float* ln1_w, const float* ln1_b,

@@ -34,6 +34,7 @@ SIGNATURES = {
     "mpnn_enc_message": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "mpnn_enc_edge_update": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "mpnn_dec_message": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
+    "mpnn_dec_message_shared": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "mpnn_node_update": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _I,
                          _P, _I, _I, _P, _I, _I, _P, _P, _P],
     "mpnn_occupancy_mlp": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
@@ -62,7 +63,7 @@ SIGNATURES = {
 
 # reduced-precision twins (one f16 product per fp32 product) of the forward entry points: same signatures
 F16_ENTRIES = ("mpnn_edge_features", "mpnn_enc_message", "mpnn_enc_edge_update", "mpnn_dec_message", "mpnn_node_update",
-               "mpnn_dec_message_subset", "mpnn_node_update_subset")
+               "mpnn_dec_message_subset", "mpnn_node_update_subset", "mpnn_dec_message_shared")
 for _n in F16_ENTRIES:
     SIGNATURES[_n + "_f16"] = SIGNATURES[_n]
 

@@ -99,7 +99,7 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
           const int* __restrict__ rank, const int* __restrict__ E_idx, const float* __restrict__ mask,
           const float* __restrict__ edge_mask, const h8* __restrict__ W1b, const h8* __restrict__ W2,
           const float* __restrict__ b2, int N, int L, int K, float* __restrict__ gsum, float* __restrict__ cnt,
-          f32x4* __restrict__ sv1, f32x4* __restrict__ sv2) {
+          f32x4* __restrict__ sv1, f32x4* __restrict__ sv2, int enc_mod) {
   __shared__ h8 lds[2 * WSPLIT];
   lds_fill(lds, W1b, WSPLIT);
   lds_fill(lds + WSPLIT, W2, WSPLIT);
@@ -115,20 +115,26 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
   if (node >= Nend) return;
 
   // per-edge scalars of a residue: gathered row, scale s (dec), reduction weight w
+  // shared-structure decoding (DEC, enc_mod < N): rows of the batch beyond the first enc_mod residues are further
+  // sequences / orders on the SAME structures; hE, E_idx, edge_mask and the encoder rows Bbuf are read at
+  // (residue % enc_mod), everything per sequence (P, A rows, rank, mask, outputs) at the residue itself
   auto setup = [&](int nd, const float* (&row)[KT], float (&s)[KT], float (&w)[KT]) {
     const int b = nd / L;
+    const int sh = (DEC && nd >= enc_mod) ? nd % enc_mod : nd;
     const float mi = mask[nd];
     int ri = 0;
     if (DEC) ri = rank[nd];
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
       const int e = 16 * c + col;
-      const int jn = b * L + E_idx[(size_t)nd * Kp + e];
+      const int jl = E_idx[(size_t)sh * Kp + e];
+      const int jn = b * L + jl;
       float em = 1.0f;
-      if (edge_mask && e < K) em = edge_mask[(size_t)nd * K + e];
+      if (edge_mask && e < K) em = edge_mask[(size_t)sh * K + e];
       if (DEC) {
         const bool before = ri > rank[jn];
-        row[c] = before ? (Abuf + (size_t)jn * lda + offA + 4 * g) : (Bbuf + (size_t)jn * ldb + offB + 4 * g);
+        const int je = (sh / L) * L + jl;
+        row[c] = before ? (Abuf + (size_t)jn * lda + offA + 4 * g) : (Bbuf + (size_t)je * ldb + offB + 4 * g);
         s[c] = mi * em;
         w[c] = e < K ? 1.0f : 0.0f;
       } else {
@@ -157,7 +163,8 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t) p[t] = row_tile(Pi, t);
     }
-    layer1_stream<KT>(W1s, hE + (size_t)node * (MPNN_NT * KT * 64) + lane, lane, h1);
+    const int node_e = (DEC && node >= enc_mod) ? node % enc_mod : node;
+    layer1_stream<KT>(W1s, hE + (size_t)node_e * (MPNN_NT * KT * 64) + lane, lane, h1);
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
@@ -582,7 +589,7 @@ extern "C" int MPNN_API(mpnn_enc_message)(const float* hE_frag, const float* PQ,
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, false, false>), grid, block, 0, (hipStream_t)stream,
                                      (const f32x4*)hE_frag, PQ, ldpq, offP, PQ, ldpq, offQ, (const float*)nullptr, 0, 0,
                                      (const int*)nullptr, E_idx32, mask, edge_mask, (const h8*)W1b_packed,
-                                     (const h8*)W2_packed, b2, N, L, K, gsum, cnt, (f32x4*)nullptr, (f32x4*)nullptr));
+                                     (const h8*)W2_packed, b2, N, L, K, gsum, cnt, (f32x4*)nullptr, (f32x4*)nullptr, N));
   MPNN_LAUNCH_CHECK();
 }
 
@@ -603,15 +610,18 @@ extern "C" int MPNN_API(mpnn_enc_edge_update)(float* hE_frag, const float* PQ, i
   MPNN_LAUNCH_CHECK();
 }
 
-extern "C" int MPNN_API(mpnn_dec_message)(const float* hE_frag, const float* PQ, int ldpq, int offPa, int offA,
-                                const float* PVenc, int ldenc, int offEnc, const int32_t* rank,
-                                const int32_t* E_idx32, const float* mask, const float* edge_mask,
-                                const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K,
-                                float* gsum, void* stream) {
+static int launch_dec_message(const char* who, const float* hE_frag, const float* PQ, int ldpq, int offPa, int offA,
+                              const float* PVenc, int ldenc, int offEnc, const int32_t* rank, const int32_t* E_idx32,
+                              const float* mask, const float* edge_mask, const float* W1b_packed,
+                              const float* W2_packed, const float* b2, int B, int n_struct, int L, int K, float* gsum,
+                              void* stream) {
   MPNN_CHECK_ARG(hE_frag && PQ && PVenc && rank && E_idx32 && mask && W1b_packed && W2_packed && b2 && gsum,
                  "mpnn_dec_message: null pointer");
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && mult4(ldpq, offPa, offA, ldenc, offEnc),
                  "mpnn_dec_message: bad sizes (strides/offsets must be multiples of 4 floats)");
+  MPNN_CHECK_ARG(n_struct >= 1 && n_struct <= B && B % n_struct == 0 && (n_struct == B || K <= 48),
+                 "mpnn_dec_message_shared: rows must be a multiple of the structures (and K <= 48)");
+  (void)who;
   const int N = B * L, KT = (K + 15) / 16;
   if (MPNN_MSG_TILEWISE || KT > 3) {
     dim3 grid(edge_grid(N, MPNN_MSGT_WAVES)), block(MPNN_MSGT_WAVES * 64);
@@ -624,8 +634,27 @@ extern "C" int MPNN_API(mpnn_dec_message)(const float* hE_frag, const float* PQ,
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, true, false>), grid, block, 0, (hipStream_t)stream,
                                      (const f32x4*)hE_frag, PQ, ldpq, offPa, PQ, ldpq, offA, PVenc, ldenc, offEnc, rank,
                                      E_idx32, mask, edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2,
-                                     N, L, K, gsum, (float*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr));
+                                     N, L, K, gsum, (float*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr, n_struct * L));
   MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int MPNN_API(mpnn_dec_message)(const float* hE_frag, const float* PQ, int ldpq, int offPa, int offA,
+                                const float* PVenc, int ldenc, int offEnc, const int32_t* rank,
+                                const int32_t* E_idx32, const float* mask, const float* edge_mask,
+                                const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K,
+                                float* gsum, void* stream) {
+  return launch_dec_message("mpnn_dec_message", hE_frag, PQ, ldpq, offPa, offA, PVenc, ldenc, offEnc, rank, E_idx32, mask,
+                            edge_mask, W1b_packed, W2_packed, b2, B, B, L, K, gsum, stream);
+}
+
+// B rows (sequences / decoding orders) on n_struct structures: row r decodes structure r % n_struct
+extern "C" int MPNN_API(mpnn_dec_message_shared)(const float* hE_frag, const float* PQ, int ldpq, int offPa, int offA,
+                                       const float* PVenc, int ldenc, int offEnc, const int32_t* rank,
+                                       const int32_t* E_idx32, const float* mask, const float* edge_mask,
+                                       const float* W1b_packed, const float* W2_packed, const float* b2, int B,
+                                       int n_struct, int L, int K, float* gsum, void* stream) {
+  return launch_dec_message("mpnn_dec_message_shared", hE_frag, PQ, ldpq, offPa, offA, PVenc, ldenc, offEnc, rank, E_idx32,
+                            mask, edge_mask, W1b_packed, W2_packed, b2, B, n_struct, L, K, gsum, stream);
 }
 
 // ---- training forward: same kernels, pre-activations saved for mpnn_edge_bwd.hip (K <= 48) ----
@@ -645,12 +674,12 @@ extern "C" int mpnn_message_train(int dec, const float* hE_frag, const float* P,
     KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, true, true>), grid, block, 0, (hipStream_t)stream,
                                        (const f32x4*)hE_frag, P, 128, 0, RowA, 128, 0, RowB, 128, 0, rank, E_idx32,
                                        mask, edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2, N, L, K, gsum,
-                                       (float*)nullptr, (f32x4*)a1_frag, (f32x4*)a2_frag));
+                                       (float*)nullptr, (f32x4*)a1_frag, (f32x4*)a2_frag, N));
   } else {
     KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, false, true>), grid, block, 0, (hipStream_t)stream,
                                        (const f32x4*)hE_frag, P, 128, 0, RowA, 128, 0, (const float*)nullptr, 0, 0,
                                        (const int*)nullptr, E_idx32, mask, edge_mask, (const h8*)W1b_packed,
-                                       (const h8*)W2_packed, b2, N, L, K, gsum, cnt, (f32x4*)a1_frag, (f32x4*)a2_frag));
+                                       (const h8*)W2_packed, b2, N, L, K, gsum, cnt, (f32x4*)a1_frag, (f32x4*)a2_frag, N));
   }
   MPNN_LAUNCH_CHECK();
 }

@@ -305,10 +305,46 @@ def forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_ord
     _require_device(X, "X")
     _lib.set_precision(getattr(model, "precision", "fp32"))
     try:
-        return _forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order, fix_backbone_noise,
-                        return_intermediates)
+        X, mask, residue_idx, chain_encoding_all, n_struct = shared_structures(X, S, mask, residue_idx,
+                                                                               chain_encoding_all)
+        B = S.shape[0]
+        if n_struct != B:
+            if (not model.training and not return_intermediates and model.features.top_k <= 48
+                    and len(model.decoder_layers) > 0):
+                return _forward_shared(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order,
+                                       fix_backbone_noise)
+            X, mask, residue_idx, chain_encoding_all = (_tile_rows(t, B) for t in
+                                                        (X, mask, residue_idx, chain_encoding_all))
+            if fix_backbone_noise is not None:
+                fix_backbone_noise = _tile_rows(fix_backbone_noise, B)
+        return _forward(model, X, S, mask, _tile_rows(chain_M, B), residue_idx, chain_encoding_all,
+                        _tile_rows(fix_order, B), fix_backbone_noise, return_intermediates)
     finally:
         _lib.set_precision("fp32")
+
+
+def _tile_rows(t, B):
+    """[n, ...] -> [B, ...] with row r = t[r % n] (the row order of shared-structure batches); None passes through."""
+    if t is None or t.shape[0] == B:
+        return t
+    return t.repeat(B // t.shape[0], *([1] * (t.dim() - 1)))
+
+
+def shared_structures(X, S, mask, residue_idx, chain_encoding_all):
+    """Batches that score many sequences on few structures (the reference's EnergyMPNN repeats one structure B times,
+    energy_mpnn.py:42-62) may pass the structure side ONCE: X / mask / residue_idx / chain_encoding_all with n rows and
+    S (chain_M, fix_order) with B = m * n rows, row r belonging to structure r % n -- or as stride-0 `expand`ed views
+    of one row.  -> the structure-side tensors cut to their n distinct rows, and n."""
+    B = S.shape[0]
+    side = (X, mask, residue_idx, chain_encoding_all)
+    n = X.shape[0]
+    if any(t.shape[0] != n for t in side):
+        raise ValueError("X, mask, residue_idx and chain_encoding_all must have the same number of rows")
+    if n == B and B > 1 and all(t.stride(0) == 0 for t in side):
+        return X[:1], mask[:1], residue_idx[:1], chain_encoding_all[:1], 1
+    if n < 1 or B % n != 0:
+        raise ValueError(f"S has {B} rows, the structure side {n}: B must be a multiple of the structures")
+    return X, mask, residue_idx, chain_encoding_all, n
 
 
 def _forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order, fix_backbone_noise,
@@ -415,6 +451,58 @@ def _forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_or
     if return_intermediates:
         inter["log_probs"] = log_probs
         return inter
+    return log_probs
+
+
+# ---------------------------------------------------------------------------
+# shared-structure forward: featurizer + encoder once per DISTINCT structure, decoder per row
+# ---------------------------------------------------------------------------
+def _forward_shared(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order, fix_backbone_noise):
+    """Same result as _forward on the materialised batch (row r = structure r % n): in eval mode featurizer and encoder
+    do not see S or the decoding order, so their outputs are computed once and every decoder kernel reads them at
+    (residue % (n L)).  Per-row state: h_V, the projections Pa | A (A carries the sequence term), rank, gsum."""
+    dev = X.device
+    mask = _f32(mask)
+    n, L = mask.shape
+    S = _i64(S)
+    B = S.shape[0]
+    m = B // n
+    Ns = B * L
+    pw = packed(model)
+    st = stream_ptr()
+    with torch.no_grad():
+        enc = _encode(model, X, mask, _i64(residue_idx), _i64(chain_encoding_all), fix_backbone_noise)
+        K = enc["K"]
+        mask_s = _tile_rows(mask, B).contiguous()
+        cm = _f32(_tile_rows(chain_M, B)) * mask_s
+        if fix_order is not None:
+            order = _i64(_tile_rows(fix_order, B))
+        else:  # reference :489-491, one draw per row
+            order = torch.argsort((cm + 0.0001) * torch.abs(torch.randn(cm.shape, device=dev)))
+        rank = torch.zeros(Ns, device=dev, dtype=torch.int32)
+        call("mpnn_order_rank", ptr(order), B, L, ptr(rank), st)
+        base = 2 * H if len(pw.enc) else 0
+        PQenc = enc["PQ"]
+        hV = enc["hV"].repeat(m, 1)
+        PQd = PQenc[:, base:base + 2 * H].repeat(m, 1)           # Pa_0 | A_0 per row ...
+        PQd[:, H:] += pw.TS[S.reshape(-1), :H]                    # ... + W1c_0 W_s[S]  (reference :478-483)
+        offPa, offA = 0, H
+        gsum = torch.empty(Ns, H, device=dev, dtype=torch.float32)
+        ldts = pw.TS.shape[1]
+        for l, lw in enumerate(pw.dec):
+            call("mpnn_dec_message_shared", ptr(enc["hE"]), ptr(PQd), PQd.shape[1], offPa, offA, ptr(PQenc),
+                 PQenc.shape[1], base + 2 * H + H * l, ptr(rank), ptr(enc["E_idx32"]), ptr(mask_s),
+                 ptr(enc["edge_mask"]), ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"]), B, n, L, K, ptr(gsum), st)
+            grp = pw.g_dec[l]
+            PQn = torch.empty(Ns, grp[2] * H, device=dev, dtype=torch.float32) if grp[2] else None
+            hVn = torch.empty_like(hV)
+            _node_update(hV, Ns, lw, gsum, None, float(K), mask_s, grp, hVn, PQn,
+                         table=(pw.TS, ldts, H * (l + 1), S, 1) if grp[2] else None)
+            hV = hVn
+            if PQn is not None:
+                PQd, offPa, offA = PQn, 0, H
+        log_probs = torch.empty(B, L, pw.n_letters, device=dev, dtype=torch.float32)
+        call("mpnn_logits_log_softmax", ptr(hV), ptr(pw.Wlogit), ptr(pw.blogit), pw.n_letters, Ns, ptr(log_probs), st)
     return log_probs
 
 

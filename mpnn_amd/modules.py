@@ -166,9 +166,20 @@ class ProteinMPNN(nn.Module):
 
     def forward(self, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order=None,
                 fix_backbone_noise=None):
-        """Graph-conditioned sequence model: log_probs [B,L,num_letters] (reference :427-529)."""
+        """Graph-conditioned sequence model: log_probs [B,L,num_letters] (reference :427-529).
+
+        Extension for scoring many sequences on few structures (the reference's EnergyMPNN repeats one structure B
+        times, energy_mpnn.py:42-62): X / mask / residue_idx / chain_encoding_all may be given with n < B rows (row r of
+        S belongs to structure r % n) or as `expand`ed stride-0 views; in eval mode featurizer and encoder then run
+        once per distinct structure.  The result equals the call on the materialised batch."""
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from . import training
+            B = S.shape[0]  # a structure side given once (engine.shared_structures) is materialised for training
+            X, mask, residue_idx, chain_encoding_all, _ = engine.shared_structures(X, S, mask, residue_idx,
+                                                                                   chain_encoding_all)
+            X, mask, chain_M, residue_idx, chain_encoding_all, fix_order, fix_backbone_noise = (
+                engine._tile_rows(t, B) for t in (X, mask, chain_M, residue_idx, chain_encoding_all, fix_order,
+                                                  fix_backbone_noise))
             return training.forward_train(self, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order,
                                           fix_backbone_noise)
         return engine.forward(self, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order,

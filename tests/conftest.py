@@ -64,7 +64,9 @@ def oracle_cfg(model_kwargs):
     return Config(k_neighbors=model_kwargs.get("k_neighbors", 32),
                   edge_cutoff=model_kwargs.get("edge_cutoff"),
                   use_virtual_center=bool(model_kwargs.get("use_virtual_center", False)),
-                  occupancy_cutoff=model_kwargs.get("occupancy_cutoff"))
+                  occupancy_cutoff=model_kwargs.get("occupancy_cutoff"),
+                  num_encoder_layers=model_kwargs.get("num_encoder_layers", 3),
+                  num_decoder_layers=model_kwargs.get("num_decoder_layers", 3))
 
 
 def untied_edge_mask(D_neighbors, D_full, rel_gap=3e-7):
