@@ -35,6 +35,9 @@ MPNN_KERNELS_BEGIN
 #ifndef MPNN_UPD_WAVES
 #define MPNN_UPD_WAVES 8
 #endif
+#ifndef MPNN_UPD_RING
+#define MPNN_UPD_RING 3  // W13 fragments in flight ahead of their MFMAs (edge update, layer 3)
+#endif
 
 // layer 1 of every edge MLP: acc += W1b * hE[node]; hE feature tiles stream from HBM one k-step
 // (two tiles) ahead of their MFMAs and are split to f16 hi/lo on the fly
@@ -329,7 +332,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
     split_gemm<KT, NKK, 0, MPNN_NT>(W2s, lane, hb, h1);
 #else
     {
-      constexpr int D = 3;
+      constexpr int D = MPNN_UPD_RING;
       h8 ah[D + 1], al[D + 1];
 #pragma unroll
       for (int q = 0; q < D; ++q) {

@@ -270,6 +270,9 @@ __global__ void k_pos_table(const float* __restrict__ W, const float* __restrict
 // Both weights stream from L2 as A fragments; outputs: hE in fragment layout and, optionally, E in the
 // reference's natural [N,K,128] layout.
 // ---------------------------------------------------------------------------
+#ifndef MPNN_FEAT_RING
+#define MPNN_FEAT_RING 4  // weight fragments in flight ahead of their MFMAs
+#endif
 template <int KT, int A, bool SAVE>
 __global__ void __launch_bounds__(256, 2)
 k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, const long long* __restrict__ residue_idx,
@@ -280,7 +283,7 @@ k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, 
                 f32x4* __restrict__ E_frag) {
   constexpr int NT_IN = A * A + 1;            // feature tiles: pairs, then positional
   constexpr int NKK_IN = (NT_IN + 1) / 2;     // k-steps of 32 features
-  constexpr int D = 3;
+  constexpr int D = MPNN_FEAT_RING;
   const int lane = threadIdx.x & 63;
   const int node = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (node >= N) return;
