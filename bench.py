@@ -213,6 +213,48 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
                     "the 21-letter head, sequence embedding, loss and optimizer are ATen ops"}
 
 
+def assembly_leg(a, dev, with_cpu):
+    """padded batches of ~10k residues out of a shard resident in HBM (mpnn_assemble_batch) beside the
+    reference's way (host featurize + host-to-device copies; the oracle's numpy restatement, one thread)."""
+    from mpnn_amd.data import StructureShard, TokenBudgetBatcher
+    from mpnn_amd.synthetic import synthetic_entries
+
+    entries = synthetic_entries(400, seed=77)
+    shard = StructureShard.from_entries(entries, shuffle=False).to(dev)
+    batches = [b for b in TokenBudgetBatcher(shard.lengths, batch_size=10000, shuffle=False, drop_overflow=False).clusters
+               if b]
+    for ids in batches[:2]:
+        shard.assemble(ids)
+    quiesce_gc()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        for ids in batches:
+            out = shard.assemble(ids)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (reps * len(batches))
+    slots = sum(len(b) * int(shard.lengths[b].max()) for b in batches) / len(batches)
+    res = {"workload": f"{len(batches)} batches under a 10000-residue padded budget from 400 synthetic multi-chain "
+                       f"structures (mean {slots:.0f} residue slots per batch)",
+           "gpu_us_per_batch": round(dt * 1e6, 1), "residue_slots_per_s": round(slots / dt, 1),
+           "algorithmic_GBps": round(slots * 141 / dt / 1e9, 2),
+           "note": "one launch per batch, ~61 B read + ~80 B written per slot: bound by launch latency, not by HBM"}
+    if with_cpu:
+        from oracle import featurize_oracle as fo
+        orders = [fo.chain_order(e, shuffle=False) for e in entries]
+        t0 = time.perf_counter()
+        n = 0
+        for ids in batches[:6]:
+            ref = fo.featurize([entries[i] for i in ids], orders=[orders[i] for i in ids])
+            moved = [torch.from_numpy(ref[k]).to(dev) for k in (0, 1, 2, 4, 5, 7)]
+            n += 1
+        torch.cuda.synchronize()
+        res["cpu_port_ms_per_batch"] = round((time.perf_counter() - t0) / n * 1e3, 2)
+        res["cpu_port"] = "oracle/featurize_oracle.py (numpy restatement of data_utils.py:51-183, 1 thread) + H2D copies"
+    return res
+
+
 def sampling_leg(a, dev, rank, world, dist, barrier):
     """BASELINE configs[4]: autoregressive sampling, random decoding order, virtual-centre node; 64 samples of one
     L=512 structure, sharded over the ranks (each rank encodes the structure once and draws its share)."""
@@ -485,6 +527,8 @@ def main():
             line["train_step"] = train
         if sampling is not None:
             line["sampling"] = sampling
+        if not a.no_f16_leg:
+            line["batch_assembly"] = assembly_leg(a, dev, with_cpu=not a.no_cpu_baseline and world == 1)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(2, L, K, iters=3)
         sys.stdout.flush()

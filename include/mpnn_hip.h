@@ -357,6 +357,24 @@ int mpnn_node_wgrad_batch(int n_jobs, const float* const* dY, const int* ldy, co
                           const int* ldx, const int* in_f, float* const* dW, const int* ldw, float* const* dbias,
                           int n_rows, float* workspace, int workspace_floats, void* stream);
 
+/* ---- batch assembly ----------------------------------------------------------------------
+ * Padded model inputs for B structures out of a flat shard in device memory, i.e. what the reference's host function
+ * featurize() returns (src/mpnn/data/data_utils.py:51-183) without its per-batch numpy work and host-to-device copies.
+ * Shard: X_cat [T,4,3] f32 (NaN = missing atom), S_cat [T] u8 (index into "ACDEFGHIKLMNPQRSTVWYX"), chain_cat [T] i32
+ * (1-based chain number in the order the chains are laid out), designed_cat [T] u8, offsets [P+1] i64 (residues of
+ * structure p are [offsets[p], offsets[p+1])).  protein_ids [B] i32 picks the structures; L_max >= their longest.
+ * Outputs, all [B, L_max]: X [.,4,3] f32 (NaN -> 0, :170-172), S i64 (pad 0), mask f32 (1 where all four atoms are
+ * finite, :171), chain_M f32, residue_idx i64 (100 (chain-1) + position, pad -100, :57,120), chain_encoding_all i64
+ * (pad 0), and lengths [B] i32. */
+int mpnn_assemble_batch(const float* X_cat, const uint8_t* S_cat, const int32_t* chain_cat, const uint8_t* designed_cat,
+                        const int64_t* offsets, const int32_t* protein_ids, int B, int L_max, float* X, int64_t* S,
+                        float* mask, float* chain_M, int64_t* residue_idx, int64_t* chain_encoding_all,
+                        int32_t* lengths, void* stream);
+
+/* mask_self [B,L,L] f32 of featurize() (data_utils.py:61,119): 0 where both residues belong to the same chain, 1
+ * elsewhere (padding included). */
+int mpnn_mask_self(const int64_t* chain_encoding_all, int B, int L, float* mask_self, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

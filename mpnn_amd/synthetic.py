@@ -151,3 +151,46 @@ def synthetic_batch(
     out = dict(X=X, S=S, mask=mask, chain_M=chain_M, residue_idx=residue_idx,
                chain_encoding_all=chain_enc, fix_order=order)
     return {k: torch.from_numpy(v).to(device) for k, v in out.items()}
+
+
+def synthetic_entries(n: int, seed: int = 0, min_len: int = 40, max_len: int = 400, max_chains: int = 4,
+                      missing_fraction: float = 0.02) -> list[dict]:
+    """Dict-of-chains entries in the format the reference's `featurize` consumes (data_utils.py:51-183; produced there
+    by the PDB parsers): `seq`, `masked_list`, `visible_list`, `seq_chain_<c>`, `coords_chain_<c>` = {`N/CA/C/O_chain_<c>`:
+    [len,3] arrays with NaN rows for unresolved atoms}.  Lengths ~ log-normal (median ~ 250, clipped), 1..max_chains
+    chains; every third entry is a homo-oligomer (a visible chain repeating a designed chain's sequence)."""
+    alphabet = "ACDEFGHIKLMNPQRSTVWYX"
+    entries = []
+    for e in range(n):
+        s0 = seed * 7919 + e * 104729
+        u = 0.5 * (hash_uniform(8, s0) + 1.0)  # [0, 1)
+        total = int(np.clip(np.exp(np.log(250.0) + 0.6 * hash_normal(1, s0 + 1)[0]), min_len, max_len))
+        n_chains = 1 + int(u[0] * max_chains) % max_chains
+        cuts = np.sort((0.5 * (hash_uniform(n_chains - 1, s0 + 2) + 1.0) * (total - 8 * n_chains)).astype(np.int64)) if n_chains > 1 \
+            else np.zeros(0, np.int64)
+        bounds = np.concatenate([[0], cuts + 8 * np.arange(1, n_chains), [total]])
+        chain_len = np.diff(bounds).astype(np.int64)
+        homo = e % 3 == 2 and n_chains >= 2
+        if homo:  # homo-oligomer: chain B is a copy of chain A's sequence (featurize compares whole chain sequences)
+            chain_len[1] = chain_len[0]
+        total = int(chain_len.sum())
+        bounds = np.concatenate([[0], np.cumsum(chain_len)])
+        X = synthetic_backbone(1, total, seed=s0 % 100003)[0].astype(np.float64)
+        miss = 0.5 * (hash_uniform(total * 4, s0 + 3).reshape(total, 4) + 1.0) < missing_fraction
+        X[miss] = np.nan
+        letters = [chr(ord("A") + c) for c in range(n_chains)]
+        entry = {"name": f"synthetic_{seed}_{e}"}
+        seqs = []
+        for c, letter in enumerate(letters):
+            lo, hi = int(bounds[c]), int(bounds[c + 1])
+            idx = (hash_u64(hi - lo, s0 + 10 + c) % np.uint64(21)).astype(np.int64)
+            seq = seqs[0] if (homo and c == 1) else "".join(alphabet[i] for i in idx)
+            seqs.append(seq)
+            entry[f"seq_chain_{letter}"] = seq
+            entry[f"coords_chain_{letter}"] = {f"{a}_chain_{letter}": X[lo:hi, k] for k, a in enumerate(("N", "CA", "C", "O"))}
+        n_masked = max(1, int(round(u[1] * n_chains)))
+        entry["masked_list"] = letters[:n_masked]
+        entry["visible_list"] = letters[n_masked:]
+        entry["seq"] = "".join(seqs)
+        entries.append(entry)
+    return entries
