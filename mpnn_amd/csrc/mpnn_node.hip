@@ -19,17 +19,24 @@ MPNN_KERNELS_BEGIN
 constexpr int NKK = MPNN_NT / 2;
 constexpr int WSPLIT = MPNN_NT * NKK * 2 * 64;  // h8 elements of one packed 128x128 split matrix
 
+#ifndef MPNN_NODE_WAVES
+#define MPNN_NODE_WAVES 4  // waves (16-node tiles) per workgroup of k_node_update
+#endif
+
 __device__ __forceinline__ void stage_matrix(const h8* __restrict__ g, h8* l) {
+#ifdef MPNN_ABL_NODMA  // timing-only ablation build: never shipped
+  return;
+#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < WSPLIT / 256; ++i) {
-    const int chunk = i * 4 + wave;  // 1 KiB per wave-instruction, LDS image is lane-linear
+  for (int i = 0; i < WSPLIT / (64 * MPNN_NODE_WAVES); ++i) {
+    const int chunk = i * MPNN_NODE_WAVES + wave;  // 1 KiB per wave-instruction, LDS image is lane-linear
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + chunk * 64 + lane),
                                      (__attribute__((address_space(3))) void*)(l + chunk * 64), 16, 0, 0);
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * MPNN_NODE_WAVES)
 k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, const float* __restrict__ cnt,
               float cnt_const, const float* __restrict__ mask, const h8* __restrict__ W3,
               const float* __restrict__ b3, const float* __restrict__ ln1w, const float* __restrict__ ln1b,
@@ -41,7 +48,7 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
               float* __restrict__ PQ, const int* __restrict__ node_list) {
   __shared__ h8 lds[2 * WSPLIT];
   const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tile = blockIdx.x * MPNN_NODE_WAVES + (threadIdx.x >> 6);
   const int g = lane >> 4, col = lane & 15;
   const int node = tile * 16 + col;
   const bool live = node < N;       // no early exit: every wave takes part in the staging barriers
@@ -336,7 +343,8 @@ extern "C" int MPNN_API(mpnn_node_update)(const float* hV_in, const float* gsum,
   if (add_table)
     MPNN_CHECK_ARG(add_idx && add_block >= 0 && add_block < nproj && ((ld_table | off_table) & 3) == 0,
                    "mpnn_node_update: bad table-add arguments");
-  hipLaunchKernelGGL(k_node_update, dim3(ceil_div(n_nodes, 64)), dim3(256), 0, (hipStream_t)stream, hV_in, gsum, cnt,
+  hipLaunchKernelGGL(k_node_update, dim3(ceil_div(n_nodes, 16 * MPNN_NODE_WAVES)), dim3(64 * MPNN_NODE_WAVES), 0,
+                     (hipStream_t)stream, hV_in, gsum, cnt,
                      cnt_const, mask, (const h8*)W3_packed, b3, ln1_w, ln1_b, (const h8*)Win_packed, b_in,
                      (const h8*)Wout_packed, b_out, ln2_w, ln2_b, 1.0f / scale, do_update,
                      (const h8*)Wproj_packed, bproj, nproj, add_table, ld_table, off_table,

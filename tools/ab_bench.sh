@@ -2,7 +2,7 @@
 # A/B kernel variants (built by tools/build_variant.sh): per-kernel ms/step for each variants/libmpnn_<tag>.so
 for so in variants/libmpnn_*.so; do
   tag=$(basename $so .so); tag=${tag#libmpnn_}
-  MPNN_HIP_LIB=$PWD/$so timeout -k 10 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f16-leg --train-batch 0 --samples 0 2>/dev/null > gpurun_out/ab_$tag.json || { echo "$tag FAILED"; continue; }
+  BENCH_NO_CHECK=1 MPNN_HIP_LIB=$PWD/$so timeout -k 10 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f16-leg --train-batch 0 --samples 0 2>/dev/null > gpurun_out/ab_$tag.json || { echo "$tag FAILED"; continue; }
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ab_$tag.json"))
