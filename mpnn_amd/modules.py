@@ -172,7 +172,9 @@ class ProteinMPNN(nn.Module):
         times, energy_mpnn.py:42-62): X / mask / residue_idx / chain_encoding_all may be given with n < B rows (row r of
         S belongs to structure r % n) or as `expand`ed stride-0 views; in eval mode featurizer and encoder then run
         once per distinct structure.  The result equals the call on the materialised batch."""
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        # autograd semantics as for any nn.Module: with grad mode on and trainable parameters the differentiable path
+        # runs (in eval mode too: no dropout, no backbone noise), inference callers use torch.no_grad()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from . import training
             B = S.shape[0]  # a structure side given once (engine.shared_structures) is materialised for training
             X, mask, residue_idx, chain_encoding_all, _ = engine.shared_structures(X, S, mask, residue_idx,

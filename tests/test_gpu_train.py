@@ -244,3 +244,29 @@ def test_edge_update_with_dropout_vs_aten(p_drop):
     for n, a, p in zip(names, got, params):
         err = float((a.double() - p.grad.double()).norm() / (p.grad.double().norm() + 1e-30))
         assert err < 1e-4, f"d{n}: relative error {err:.2e}"
+
+
+def test_eval_mode_with_grad_enabled_is_differentiable():
+    """Fine-tuning in eval mode (no dropout, no backbone noise) must still reach the parameters: with grad mode on the
+    module takes the differentiable path whatever its training flag; under no_grad it takes the inference kernels,
+    and both give the same log-probs."""
+    from mpnn_amd import training
+    from mpnn_amd.synthetic import synthetic_batch
+
+    kw = dict(k_neighbors=30)
+    model = build(kw, dropout=0.1, augment_eps=0.1).eval()   # eval: the dropout / noise settings must not act
+    b = synthetic_batch(2, 72, seed=12, lengths=[72, 60], n_chains=2)
+    g = {k: v.cuda() for k, v in b.items()}
+    args = (g["X"], g["S"], g["mask"], g["chain_M"], g["residue_idx"], g["chain_encoding_all"])
+    lp = model(*args, fix_order=g["fix_order"])
+    assert lp.requires_grad
+    with torch.no_grad():
+        lp_inf = model(*args, fix_order=g["fix_order"])
+    assert not lp_inf.requires_grad
+    assert (lp.detach() - lp_inf).abs().max().item() <= 1e-5
+    _, loss = training.loss_smoothed(g["S"], lp, g["mask"] * g["chain_M"])
+    loss.backward()
+    got = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+    loss_ref, _, want = oracle_loss_and_grads(model, kw, b)
+    assert abs(loss.item() - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref))
+    compare_grads({n: got.get(n, torch.zeros_like(v)) for n, v in want.items()}, want)
