@@ -9,7 +9,18 @@ namespace {
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 
 __device__ __forceinline__ void lds_fill(h8* dst, const h8* __restrict__ src, int n) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+  // batches of 8 loads in flight per thread before their LDS writes (a plain copy loop waits for every load in turn,
+  // which is what a short-lived workgroup - the sampler's level kernels - spends most of its time on)
+  const int stride = blockDim.x;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * stride) {
+    h8 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * stride < n) v[u] = src[i0 + u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * stride < n) dst[i0 + u * stride] = v[u];
+  }
 }
 
 __device__ __forceinline__ f32x4 row_tile(const float* row, int t) {

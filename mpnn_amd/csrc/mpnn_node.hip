@@ -373,7 +373,8 @@ extern "C" int MPNN_API(mpnn_node_update_subset)(const float* hV_in, float* gsum
 #ifndef MPNN_FAST
 MPNN_KERNELS_BEGIN
 // ---------------------------------------------------------------------------
-// Sampling head for a listed subset of residues (one wave = 16 residues):
+// Sampling head for a listed subset of residues (one workgroup = 16 residues: wave 0 draws, all four waves fold
+// the sequence terms into the gathered rows):
 //   logits = W_out h + b;  log_probs = log_softmax(logits)  (the model's distribution, what a teacher-forced
 //   forward returns at this position);  S ~ softmax((logits + bias) / temperature)  by inverse CDF with a
 //   counter-based uniform u(seed, residue);  fixed residues (designable[n] == 0) keep S_in[n].
@@ -400,12 +401,13 @@ k_sample(const float* __restrict__ hV, const f32x4* __restrict__ Wp, const float
          float inv_temperature, unsigned long long seed, const float* __restrict__ designable,
          const long long* __restrict__ S_in, long long* __restrict__ S_out, float* __restrict__ log_probs,
          const float* __restrict__ TS, int ld_ts, SampleRows rows) {
-  __shared__ float pr[4][16][33];
-  __shared__ int pick[4][16];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int tile = blockIdx.x * 4 + wv;
-  if (tile * 16 >= N) return;
+  __shared__ float pr[1][16][33];
+  __shared__ int pick[1][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int wv = 0;
+  const int tile = blockIdx.x;  // host: grid = ceil(N / 16), so tile * 16 < N
   const int g = lane >> 4, col = lane & 15;
+  if (wave == 0) {
   const int idx = tile * 16 + col;
   const bool live = idx < N;
   const int nd = node_list[live ? idx : N - 1];
@@ -419,7 +421,9 @@ k_sample(const float* __restrict__ hV, const f32x4* __restrict__ Wp, const float
       const int letter = 16 * t + 4 * g + r;
       y[t][0][r] = letter < n_letters ? bias[letter] : 0.f;
     }
+#ifndef MPNN_ABL_SAMPLE_NOGEMM
   tile_gemm<1, MPNN_NT, 0, 2>(Wp, lane, h, y);
+#endif
   // model log-probs
   float mx = -INFINITY;
 #pragma unroll
@@ -463,7 +467,11 @@ k_sample(const float* __restrict__ hV, const f32x4* __restrict__ Wp, const float
   __builtin_amdgcn_wave_barrier();
   if (g == 0) {
     int s = 0;
+#ifdef MPNN_ABL_SAMPLE_NOLOOP
+    if (false) {
+#else
     if (designable[nd] != 0.f) {
+#endif
       float tot = 0.f;
       for (int a = 0; a < n_letters; ++a) tot += pr[wv][col][a];
       const float u = uniform01(seed, (unsigned long long)nd) * tot;
@@ -479,28 +487,36 @@ k_sample(const float* __restrict__ hV, const f32x4* __restrict__ Wp, const float
     pick[wv][col] = s;
     if (live) S_out[nd] = s;
   }
-  __builtin_amdgcn_s_waitcnt(0);
-  __builtin_amdgcn_wave_barrier();
-  // fold the sequence term of the chosen letter into every decoder layer's A rows (2 floats per lane per row)
+  }  // wave 0
+  __syncthreads();
+  // fold the sequence term of the chosen letter into every decoder layer's A rows (2 floats per lane per row); the
+  // rows belong to this residue alone until later levels gather them, so plain read-modify-write; the 16 x n_layers
+  // row updates are dealt round-robin to the four waves, each with all its loads in flight before the first store
+#ifdef MPNN_ABL_SAMPLE_NOTAIL  // timing-only ablation build: never shipped
+  return;
+#endif
   const int nlive = min(16, N - tile * 16);
-  for (int l = 0; l < rows.n_layers; ++l) {  // 16 independent row updates in flight per layer
-    float2 v[16], add[16];
+  const int nupd = nlive * rows.n_layers;
+  constexpr int MAXU = 16;  // 16 residues x 4 layers / 4 waves
+  float2 v[MAXU], add[MAXU];
+  float2* dst[MAXU];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      if (c < nlive) {
-        const int n = node_list[tile * 16 + c], s = pick[wv][c];
-        v[c] = *(reinterpret_cast<const float2*>(rows.A[l] + (size_t)n * rows.ld[l] + rows.off[l]) + lane);
-        add[c] = *(reinterpret_cast<const float2*>(TS + (size_t)s * ld_ts + l * MPNN_H) + lane);
-      }
+  for (int i = 0; i < MAXU; ++i) {
+    const int u = wave + 4 * i;
+    if (u < nupd) {
+      const int c = u % nlive, l = u / nlive;
+      const int n = node_list[tile * 16 + c], s = pick[wv][c];
+      dst[i] = reinterpret_cast<float2*>(rows.A[l] + (size_t)n * rows.ld[l] + rows.off[l]) + lane;
+      v[i] = *dst[i];
+      add[i] = *(reinterpret_cast<const float2*>(TS + (size_t)s * ld_ts + l * MPNN_H) + lane);
     }
+  }
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      if (c < nlive) {
-        const int n = node_list[tile * 16 + c];
-        v[c].x += add[c].x;
-        v[c].y += add[c].y;
-        *(reinterpret_cast<float2*>(rows.A[l] + (size_t)n * rows.ld[l] + rows.off[l]) + lane) = v[c];
-      }
+  for (int i = 0; i < MAXU; ++i) {
+    if (wave + 4 * i < nupd) {
+      v[i].x += add[i].x;
+      v[i].y += add[i].y;
+      *dst[i] = v[i];
     }
   }
 }
@@ -525,7 +541,7 @@ extern "C" int mpnn_sample_subset(const float* hV, const float* Wout_packed, con
     rows.ld[l] = l < n_layers ? A_ld[l] : 0;
     rows.off[l] = l < n_layers ? A_off[l] : 0;
   }
-  hipLaunchKernelGGL(k_sample, dim3(ceil_div(n_list, 64)), dim3(256), 0, (hipStream_t)stream, hV,
+  hipLaunchKernelGGL(k_sample, dim3(ceil_div(n_list, 16)), dim3(256), 0, (hipStream_t)stream, hV,
                      (const f32x4*)Wout_packed, bias, logit_bias, n_letters, node_list, n_list, 1.0f / temperature,
                      (unsigned long long)seed, designable, (const long long*)S_in, (long long*)S_out, log_probs, TS,
                      ld_ts, rows);
