@@ -156,6 +156,9 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
 // partial results meet through a 32 KiB LDS exchange buffer, weights stream straight from L2.  Same maths as
 // k_node_update (cnt = cnt_const, no table add); reads AND RE-ZEROES its gsum rows (k_message_level accumulates).
 // ---------------------------------------------------------------------------
+#ifndef MPNN_LEVEL_RING
+#define MPNN_LEVEL_RING 8  // weight fragments in flight per wave (L2 -> registers) in k_node_update_level
+#endif
 __global__ void __launch_bounds__(256)
 k_node_update_level(const float* __restrict__ hV_in, float* __restrict__ gsum, float cnt_const,
                     const float* __restrict__ mask, const h8* __restrict__ W3, const float* __restrict__ b3,
@@ -183,7 +186,7 @@ k_node_update_level(const float* __restrict__ hV_in, float* __restrict__ gsum, f
     f32x4 d2[2][1];
 #pragma unroll
     for (int i = 0; i < 2; ++i) d2[i][0] = *reinterpret_cast<const f32x4*>(b3 + 16 * (2 * wave + i) + 4 * g) * cnt_const;
-    split_gemm_stream<1, NKK, 2, 7>(W3 + (size_t)(2 * wave) * NKK * 2 * 64 + lane, xb, d2);
+    split_gemm_stream<1, NKK, 2, (MPNN_LEVEL_RING < 7 ? MPNN_LEVEL_RING : 7)>(W3 + (size_t)(2 * wave) * NKK * 2 * 64 + lane, xb, d2);
     ex[0][2 * wave][lane] = d2[0][0];
     ex[0][2 * wave + 1][lane] = d2[1][0];
   }
@@ -205,10 +208,10 @@ k_node_update_level(const float* __restrict__ hV_in, float* __restrict__ gsum, f
       hid[t][0] = *reinterpret_cast<const f32x4*>(bin + 128 * wave + 16 * t + 4 * g);
       o[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    split_gemm_stream<1, NKK, MPNN_NT, 8>(Win + (size_t)wave * WSPLIT + lane, xb, hid);
+    split_gemm_stream<1, NKK, MPNN_NT, MPNN_LEVEL_RING>(Win + (size_t)wave * WSPLIT + lane, xb, hid);
     BFrag hb[NKK][1];
     tile_to_bfrag<MPNN_NT, 1, true>(hid, hb);
-    split_gemm_stream<1, NKK, MPNN_NT, 8>(Wout + (size_t)wave * WSPLIT + lane, hb, o);
+    split_gemm_stream<1, NKK, MPNN_NT, MPNN_LEVEL_RING>(Wout + (size_t)wave * WSPLIT + lane, hb, o);
   }
   __syncthreads();  // every wave has read the W3 exchange
 #pragma unroll
@@ -234,7 +237,7 @@ k_node_update_level(const float* __restrict__ hV_in, float* __restrict__ gsum, f
     f32x4 y[4][1];
 #pragma unroll
     for (int i = 0; i < 4; ++i) y[i][0] = *reinterpret_cast<const f32x4*>(bproj + p * MPNN_H + 16 * (t0 + i) + 4 * g);
-    split_gemm_stream<1, NKK, 4, 8>(Wproj + (size_t)p * WSPLIT + (size_t)t0 * NKK * 2 * 64 + lane, pb, y);
+    split_gemm_stream<1, NKK, 4, (MPNN_LEVEL_RING < 15 ? MPNN_LEVEL_RING : 15)>(Wproj + (size_t)p * WSPLIT + (size_t)t0 * NKK * 2 * 64 + lane, pb, y);
     if (live) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
