@@ -105,3 +105,33 @@ def test_hip_graph_replay_is_bit_identical():
         with torch.no_grad():
             ref = model(*[b[k] for k in keys[:6]], fix_order=b["fix_order"])
         assert torch.equal(g(*[b[k] for k in keys]), ref)
+
+
+@pytest.mark.parametrize("kw,B,L", [
+    (dict(k_neighbors=64), 2, 100),                               # four full neighbour tiles (tile-wise message kernel)
+    (dict(k_neighbors=56, use_virtual_center=True), 2, 90),       # partial fourth tile, 36 atom pairs
+    (dict(k_neighbors=64, edge_cutoff=16.0), 1, 60),              # K' = min(k, L) = 60 with an edge mask
+])
+def test_more_than_48_neighbours(kw, B, L):
+    """The largest neighbourhoods the module accepts (k <= 64): every kernel's fourth column tile."""
+    from mpnn_amd.synthetic import synthetic_batch
+
+    model = build_model(kw)
+    b = synthetic_batch(B=B, L=L, seed=300 + L, lengths=[L] + [L - 13] * (B - 1), n_chains=2, design_fraction=0.5)
+    rec = {n: v.numpy() for n, v in b.items()}
+    out = run_hip(model, rec)
+    ref = run_oracle(model, kw, rec)
+    same(out["E_idx"].cpu().numpy(), ref["E_idx"].numpy(), "E_idx")
+    same(out["mask_bw"].cpu().numpy(), ref["mask_bw"].numpy(), "mask_bw")
+    same(out["mask_fw"].cpu().numpy(), ref["mask_fw"].numpy(), "mask_fw")
+    m = rec["mask"].astype(bool)
+    assert_close(out["log_probs"].cpu().numpy()[m], ref["log_probs"].numpy()[m], LP_RTOL, LP_ATOL, "log_probs")
+    for got, want in zip(out["h_V_dec"], ref["h_V_dec"]):
+        assert_close(got.cpu().numpy()[m], want.numpy()[m], 1e-4, 1e-5, "h_V_dec")
+    # the differentiable and sampling paths cover k <= 48 and say so
+    d = {k: v.cuda() for k, v in b.items()}
+    args = (d["X"], d["S"], d["mask"], d["chain_M"], d["residue_idx"], d["chain_encoding_all"])
+    with pytest.raises(NotImplementedError):
+        model(*args)                                   # grad mode on: differentiable path
+    with pytest.raises(NotImplementedError):
+        model.sample(d["X"], d["mask"], d["chain_M"], d["residue_idx"], d["chain_encoding_all"])
