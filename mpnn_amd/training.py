@@ -550,8 +550,33 @@ def loss_smoothed(S, log_probs, mask, weight=0.1):
     return loss, torch.sum(loss * mask) / 2000.0
 
 
-def train_step(model, optimizer, batch, world_size=1, fix_order=None, fix_backbone_noise=None):
-    """One optimisation step (reference train.py:130-175): forward, smoothed loss, backward, (all-reduce), step."""
+def loss_nll(S, log_probs, mask):
+    """Per-residue NLL, its masked mean and the per-residue argmax hits (reference train.py:51-60; the metrics the
+    reference's loop accumulates after every step, :397-399)."""
+    loss = -log_probs.gather(-1, S.unsqueeze(-1)).squeeze(-1)
+    true_false = torch.argmax(log_probs, -1) == S
+    return loss, torch.sum(loss * mask) / torch.sum(mask), true_false
+
+
+def make_optimizer(model, lr=1e-3, weight_decay=1e-2, total_steps=None):
+    """AdamW and, when `total_steps` is given, the reference's schedule (train.py:217-222): linear warm-up from 1e-8 over
+    the first 1 % of the steps, then cosine annealing to 0.  The optimizer is torch's fused (multi-tensor) AdamW: one
+    launch for all 1.66 M parameters.  -> (optimizer, scheduler or None)."""
+    from torch.optim.lr_scheduler import CosineAnnealingLR, LinearLR, SequentialLR
+    fused = all(p.is_cuda for p in model.parameters())
+    optimizer = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay, fused=fused)
+    if total_steps is None:
+        return optimizer, None
+    warmup_steps = int(0.01 * total_steps)
+    warmup = LinearLR(optimizer, start_factor=1e-8, total_iters=warmup_steps)
+    cosine = CosineAnnealingLR(optimizer, T_max=max(1, total_steps - warmup_steps), eta_min=0.0)
+    return optimizer, SequentialLR(optimizer, schedulers=[warmup, cosine], milestones=[warmup_steps])
+
+
+def train_step(model, optimizer, batch, world_size=1, fix_order=None, fix_backbone_noise=None, scheduler=None,
+               max_grad_norm=0.0):
+    """One optimisation step (reference train.py:376-395): forward, smoothed loss, backward, (gradient all-reduce),
+    optional gradient-norm clipping (:389-390), optimizer and scheduler step."""
     from . import distributed
     X, S, mask, chain_M, residue_idx, chain_enc = batch
     optimizer.zero_grad(set_to_none=True)
@@ -560,5 +585,9 @@ def train_step(model, optimizer, batch, world_size=1, fix_order=None, fix_backbo
     _, loss = loss_smoothed(S, log_probs, mask_for_loss)
     loss.backward()
     distributed.allreduce_gradients(model.parameters(), world_size)  # no-op for a single rank
+    if max_grad_norm and max_grad_norm > 0.0:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
     optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
     return loss.detach(), log_probs.detach()

@@ -162,13 +162,18 @@ def test_train_steps_reduce_loss(dropout, augment_eps):
     torch.manual_seed(0)
     b = synthetic_batch(B=4, L=96, seed=21, lengths=[96, 80, 64, 50], n_chains=2, design_fraction=0.8)
     model = build(dict(k_neighbors=48), dropout=dropout, augment_eps=augment_eps)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2)
+    # the reference's recipe when dropout is on: fused AdamW + warm-up/cosine schedule + gradient-norm clipping
+    opt, sched = training.make_optimizer(model, lr=1e-3, total_steps=100) if dropout else \
+        (torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2), None)
     d = "cuda"
     batch = tuple(b[k].to(d) for k in ("X", "S", "mask", "chain_M", "residue_idx", "chain_encoding_all"))
     losses = []
     for _ in range(8):
-        loss, _ = training.train_step(model, opt, batch, fix_order=b["fix_order"].to(d))
+        loss, lp = training.train_step(model, opt, batch, fix_order=b["fix_order"].to(d), scheduler=sched,
+                                       max_grad_norm=1.0 if dropout else 0.0)
         losses.append(float(loss))
+    _, nll, hits = training.loss_nll(batch[1], lp, batch[2] * batch[3])
+    assert np.isfinite(float(nll)) and hits.shape == (4, 96)
     assert all(np.isfinite(losses)), losses
     assert min(losses[-2:]) < losses[0], losses
     assert all(torch.isfinite(p).all() for p in model.parameters())

@@ -73,3 +73,33 @@ def test_cpu_input_fails_loudly():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         with torch.no_grad():
             m(b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
+
+
+def test_optimizer_schedule_and_nll_match_the_reference_recipe():
+    """train.py:217-222: AdamW(wd 1e-2), LinearLR(1e-8 -> 1 over 1 % of the steps) then cosine to 0; train.py:51-60."""
+    import math
+
+    import torch
+
+    from mpnn_amd import training
+
+    lin = torch.nn.Linear(4, 3)
+    opt, sched = training.make_optimizer(lin, lr=2e-3, total_steps=1000)
+    assert isinstance(opt, torch.optim.AdamW) and opt.defaults["weight_decay"] == 1e-2
+    lrs = []
+    for _ in range(1000):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sched.step()
+    assert abs(lrs[0] - 2e-3 * 1e-8) < 1e-12 and abs(lrs[10] - 2e-3) < 1e-9      # warm-up = 10 steps
+    assert all(lrs[i] < lrs[i + 1] for i in range(10)) and all(lrs[i] >= lrs[i + 1] for i in range(10, 999))
+    assert abs(lrs[10 + 495] - 2e-3 * 0.5 * (1 + math.cos(math.pi * 495 / 990))) < 1e-9
+    assert training.make_optimizer(lin)[1] is None
+    g = torch.Generator().manual_seed(0)
+    lp = torch.log_softmax(torch.randn(2, 5, 21, generator=g), -1)
+    S = torch.randint(0, 21, (2, 5), generator=g)
+    mask = (torch.rand(2, 5, generator=g) < 0.7).float()
+    loss, loss_av, hits = training.loss_nll(S, lp, mask)
+    ref = torch.nn.NLLLoss(reduction="none")(lp.view(-1, 21), S.view(-1)).view(2, 5)
+    assert torch.equal(loss, ref) and torch.equal(hits, lp.argmax(-1) == S)
+    assert torch.allclose(loss_av, (ref * mask).sum() / mask.sum())
