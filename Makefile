@@ -4,7 +4,7 @@ ARCH  ?= gfx950
 CSRC  := mpnn_amd/csrc
 OUT   := mpnn_amd/libmpnn_hip.so
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wno-unused-result $(EXTRA)
-OBJS  := $(CSRC)/mpnn_featurizer.o $(CSRC)/mpnn_edge.o $(CSRC)/mpnn_edge_bwd.o $(CSRC)/mpnn_node.o $(CSRC)/mpnn_node_bwd.o $(CSRC)/mpnn_data.o $(CSRC)/mpnn_abi.o \
+OBJS  := $(CSRC)/mpnn_featurizer.o $(CSRC)/mpnn_edge.o $(CSRC)/mpnn_edge_bwd.o $(CSRC)/mpnn_node.o $(CSRC)/mpnn_node_bwd.o $(CSRC)/mpnn_data.o $(CSRC)/mpnn_loss.o $(CSRC)/mpnn_abi.o \
          $(CSRC)/mpnn_featurizer_f16.o $(CSRC)/mpnn_edge_f16.o $(CSRC)/mpnn_node_f16.o
 
 all: $(OUT)
@@ -23,6 +23,9 @@ $(CSRC)/mpnn_abi.o: $(CSRC)/mpnn_abi.cpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/mpnn_data.o: $(CSRC)/mpnn_data.hip $(CSRC)/mpnn_common.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(CSRC)/mpnn_loss.o: $(CSRC)/mpnn_loss.hip $(CSRC)/mpnn_common.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(OUT): $(OBJS)

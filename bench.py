@@ -209,8 +209,8 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
                                  "4.3-4.5 TB/s, the weight-gradient pass at 3.6 TB/s (PMC-confirmed bytes)"},
             "final_loss": round(float(loss), 6),
             "hip_kernels_ms_per_step": kern, "hip_kernels_total_ms": round(hip_ms, 3),
-            "note": "forward, backward and weight gradients of the featurizer, edge and node stages are HIP kernels; "
-                    "the 21-letter head, sequence embedding, loss and optimizer are ATen ops"}
+            "note": "forward, backward and weight gradients of the featurizer, edge and node stages, the output head "
+                    "and the smoothed loss are HIP kernels; sequence embedding and optimizer (fused AdamW) are ATen ops"}
 
 
 def assembly_leg(a, dev, with_cpu):

@@ -357,6 +357,19 @@ int mpnn_node_wgrad_batch(int n_jobs, const float* const* dY, const int* ldy, co
                           const int* ldx, const int* in_f, float* const* dW, const int* ldw, float* const* dbias,
                           int n_rows, float* workspace, int workspace_floats, void* stream);
 
+/* ---- output head backward and loss ---------------------------------------------------------
+ * Backward of mpnn_logits_log_softmax (reference model_utils.py :527-528): d_logits = d_log_probs - exp(log_probs) *
+ * rowsum(d_log_probs); d_hV [n_nodes,128] = d_logits W_out; dW [n_letters,128] += d_logits^T hV; db [n_letters] +=
+ * column sums (dW / db accumulate: zero them first; db may be NULL).  W_out is the nn.Linear weight, row-major. */
+int mpnn_logits_log_softmax_bwd(const float* d_log_probs, const float* log_probs, const float* hV, const float* W_out,
+                                int n_letters, int n_nodes, float* d_hV, float* dW, float* db, void* stream);
+
+/* loss_smoothed of the reference's training loop (train.py:63-73): t = (one_hot(S) + weight / n_letters) normalised,
+ * loss [n_nodes] = -sum_a t log_probs, loss_sum += scale * sum_n loss mask (scale = 1/2000 there; zero loss_sum first),
+ * and, when d_log_probs is given, the gradient of loss_sum: -t mask scale. */
+int mpnn_loss_smoothed(const float* log_probs, const int64_t* S, const float* mask, int n_nodes, int n_letters,
+                       float weight, float scale, float* loss, float* loss_sum, float* d_log_probs, void* stream);
+
 /* ---- batch assembly ----------------------------------------------------------------------
  * Padded model inputs for B structures out of a flat shard in device memory, i.e. what the reference's host function
  * featurize() returns (src/mpnn/data/data_utils.py:51-183) without its per-batch numpy work and host-to-device copies.

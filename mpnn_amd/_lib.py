@@ -58,6 +58,8 @@ SIGNATURES = {
     "mpnn_node_update_bwd": [_P] * 6 + [_F] + [_P] * 4 + [_F, _P, _I, _P, _P, _P, _I] + [_P] * 8 + [_F, ctypes.c_uint32, _P],
     "mpnn_node_wgrad_batch": [_I] + [_P] * 9 + [_I, _P, _I, _P],
     "mpnn_pack_blocks": [_P, _P, _P, _I, _P, _P],
+    "mpnn_logits_log_softmax_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "mpnn_loss_smoothed": [_P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _P],
     "mpnn_assemble_batch": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "mpnn_mask_self": [_P, _I, _I, _P, _P],
     "mpnn_node_wgrad": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P],

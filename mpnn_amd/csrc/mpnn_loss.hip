@@ -1,0 +1,147 @@
+// Output head backward and the label-smoothed loss (SURVEY section 8f "next" N3).
+//   log_probs = log_softmax(W_out h + b)                         (reference model_utils.py :527-528)
+//   loss_smoothed(S, log_probs, mask)                            (reference train.py :63-73)
+// The forward of the head is mpnn_logits_log_softmax (mpnn_node.hip).  Everything here is tiny (N x 21 against the
+// N x 48 x 128 edge tensors): the point is one launch each instead of a dozen ATen launches, and no host sync.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mpnn_common.h"
+
+namespace {
+
+constexpr int HB_NODES = 64;    // nodes per workgroup
+constexpr int HB_MAXL = 32;     // letters (padded)
+
+// d_logits = d_logp - softmax * sum(d_logp);  d_hV = d_logits W;  dW += d_logits^T hV;  db += sum_n d_logits
+__global__ void __launch_bounds__(256)
+k_head_bwd(const float* __restrict__ d_logp, const float* __restrict__ logp, const float* __restrict__ hV,
+           const float* __restrict__ W, int N, int n_letters, float* __restrict__ d_hV, float* __restrict__ dW,
+           float* __restrict__ db) {
+  __shared__ float dl[HB_NODES][HB_MAXL + 1];
+  __shared__ float Wl[HB_MAXL][MPNN_H];
+  __shared__ float hv[HB_NODES][MPNN_H + 4];
+  const int tid = threadIdx.x;
+  const int n0 = blockIdx.x * HB_NODES;
+  for (int i = tid; i < HB_MAXL * MPNN_H; i += 256) {
+    const int a = i / MPNN_H;
+    Wl[a][i % MPNN_H] = a < n_letters ? W[i] : 0.f;
+  }
+  for (int i = tid; i < HB_NODES * (MPNN_H / 4); i += 256) {
+    const int n = i / (MPNN_H / 4), q = i % (MPNN_H / 4);
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (n0 + n < N) v = *reinterpret_cast<const f32x4*>(hV + (size_t)(n0 + n) * MPNN_H + 4 * q);
+    hv[n][4 * q] = v.x; hv[n][4 * q + 1] = v.y; hv[n][4 * q + 2] = v.z; hv[n][4 * q + 3] = v.w;
+  }
+  {  // four threads per node share its letters
+    const int n = tid >> 2, q = tid & 3;
+    const bool live = n0 + n < N;
+    float g[HB_MAXL / 4], p[HB_MAXL / 4], s = 0.f;
+#pragma unroll
+    for (int u = 0; u < HB_MAXL / 4; ++u) {
+      const int a = q + 4 * u;
+      g[u] = p[u] = 0.f;
+      if (live && a < n_letters) {
+        g[u] = d_logp[(size_t)(n0 + n) * n_letters + a];
+        p[u] = __expf(logp[(size_t)(n0 + n) * n_letters + a]);
+      }
+      s += g[u];
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+#pragma unroll
+    for (int u = 0; u < HB_MAXL / 4; ++u) dl[n][q + 4 * u] = g[u] - p[u] * s;
+  }
+  __syncthreads();
+  {  // d_hV: thread = (node, 32-feature block)
+    const int n = tid >> 2, f0 = (tid & 3) * 32;
+    float acc[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+    for (int a = 0; a < n_letters; ++a) {
+      const float d = dl[n][a];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) acc[j] = fmaf(d, Wl[a][f0 + j], acc[j]);
+    }
+    if (n0 + n < N) {
+#pragma unroll
+      for (int j = 0; j < 32; j += 4)
+        *reinterpret_cast<f32x4*>(d_hV + (size_t)(n0 + n) * MPNN_H + f0 + j) =
+            f32x4{acc[j], acc[j + 1], acc[j + 2], acc[j + 3]};
+    }
+  }
+  {  // dW partial of this workgroup: thread = (feature, letter parity)
+    const int f = tid & (MPNN_H - 1), a0 = tid >> 7;
+    float acc[HB_MAXL / 2];
+#pragma unroll
+    for (int u = 0; u < HB_MAXL / 2; ++u) acc[u] = 0.f;
+    for (int n = 0; n < HB_NODES; ++n) {
+      const float h = hv[n][f];
+#pragma unroll
+      for (int u = 0; u < HB_MAXL / 2; ++u) acc[u] = fmaf(dl[n][a0 + 2 * u], h, acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < HB_MAXL / 2; ++u) {
+      const int a = a0 + 2 * u;
+      if (a < n_letters) unsafeAtomicAdd(dW + (size_t)a * MPNN_H + f, acc[u]);
+    }
+  }
+  if (db && tid < n_letters) {
+    float s = 0.f;
+    for (int n = 0; n < HB_NODES; ++n) s += dl[n][tid];
+    unsafeAtomicAdd(db + tid, s);
+  }
+}
+
+// loss[n] = -sum_a t[n,a] logp[n,a],  t = (onehot(S) + weight / A) / (1 + weight);   loss_sum += sum_n loss mask * scale;
+// d_logp[n,a] = -t[n,a] mask[n] scale   (the gradient of loss_sum)
+__global__ void __launch_bounds__(256)
+k_loss_smoothed(const float* __restrict__ logp, const long long* __restrict__ S, const float* __restrict__ mask, int N,
+                int n_letters, float weight, float scale, float* __restrict__ loss, float* __restrict__ loss_sum,
+                float* __restrict__ d_logp) {
+  __shared__ float part[4];
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  float contrib = 0.f;
+  if (n < N) {
+    const int s = (int)S[n];
+    const float m = mask[n];
+    const float base = weight / (float)n_letters;
+    float tot = 0.f;  // the reference normalises by the actual sum of the smoothed row (train.py:69)
+    for (int a = 0; a < n_letters; ++a) tot += (a == s ? 1.f : 0.f) + base;
+    float l = 0.f;
+    for (int a = 0; a < n_letters; ++a) {
+      const float t = ((a == s ? 1.f : 0.f) + base) / tot;
+      l -= t * logp[(size_t)n * n_letters + a];
+      if (d_logp) d_logp[(size_t)n * n_letters + a] = -t * m * scale;
+    }
+    loss[n] = l;
+    contrib = l * m * scale;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) contrib += __shfl_xor(contrib, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = contrib;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss_sum, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+}  // namespace
+
+extern "C" int mpnn_logits_log_softmax_bwd(const float* d_log_probs, const float* log_probs, const float* hV,
+                                           const float* W_out, int n_letters, int n_nodes, float* d_hV, float* dW,
+                                           float* db, void* stream) {
+  MPNN_CHECK_ARG(d_log_probs && log_probs && hV && W_out && d_hV && dW, "mpnn_logits_log_softmax_bwd: null pointer");
+  MPNN_CHECK_ARG(n_nodes > 0 && n_letters >= 1 && n_letters <= HB_MAXL, "mpnn_logits_log_softmax_bwd: bad sizes");
+  hipLaunchKernelGGL(k_head_bwd, dim3((n_nodes + HB_NODES - 1) / HB_NODES), dim3(256), 0, (hipStream_t)stream,
+                     d_log_probs, log_probs, hV, W_out, n_nodes, n_letters, d_hV, dW, db);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_loss_smoothed(const float* log_probs, const int64_t* S, const float* mask, int n_nodes,
+                                  int n_letters, float weight, float scale, float* loss, float* loss_sum,
+                                  float* d_log_probs, void* stream) {
+  MPNN_CHECK_ARG(log_probs && S && mask && loss && loss_sum, "mpnn_loss_smoothed: null pointer");
+  MPNN_CHECK_ARG(n_nodes > 0 && n_letters >= 1, "mpnn_loss_smoothed: bad sizes");
+  hipLaunchKernelGGL(k_loss_smoothed, dim3((n_nodes + 255) / 256), dim3(256), 0, (hipStream_t)stream, log_probs,
+                     (const long long*)S, mask, n_nodes, n_letters, weight, scale, loss, loss_sum, d_log_probs);
+  MPNN_LAUNCH_CHECK();
+}

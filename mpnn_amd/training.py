@@ -536,8 +536,69 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
             hV, pr = _node_update(lyr, hV, gsum, cnt, g.mask, p_drop, nxt)
             if pr:
                 Pa, A0 = pr
-    logits = linear(hV, model.W_out.weight, model.W_out.bias)
-    return F.log_softmax(logits, dim=-1).view(B, L, -1)
+    return HeadFn.apply(hV, model.W_out.weight, model.W_out.bias).view(B, L, -1)
+
+
+class HeadFn(torch.autograd.Function):
+    """log_softmax(W_out h + b) (reference :527-528): mpnn_logits_log_softmax forward, mpnn_logits_log_softmax_bwd
+    backward (d_logits, d_hV, dW, db in one launch)."""
+
+    @staticmethod
+    def forward(ctx, hV, W, bias):
+        N, n_letters = hV.shape[0], W.shape[0]
+        W = W.detach().float().contiguous()
+        nto, nti = (n_letters + 15) // 16, H // 16
+        Wp = torch.empty(nto * nti * 256, device=hV.device, dtype=torch.float32)
+        st = stream_ptr()
+        call("mpnn_pack_linear", ptr(W), n_letters, H, H, 0, ptr(Wp), st)
+        b = bias.detach().float().contiguous()
+        hV = hV.contiguous()
+        logp = torch.empty(N, n_letters, device=hV.device, dtype=torch.float32)
+        call("mpnn_logits_log_softmax", ptr(hV), ptr(Wp), ptr(b), n_letters, N, ptr(logp), st)
+        ctx.save_for_backward(hV, W, logp)
+        return logp
+
+    @staticmethod
+    def backward(ctx, d_logp):
+        hV, W, logp = ctx.saved_tensors
+        N, n_letters = logp.shape
+        d_logp = d_logp.contiguous().float()
+        d_hV = torch.empty_like(hV)
+        dW = _zeros(hV.device, n_letters, H)
+        db = _zeros(hV.device, n_letters)
+        call("mpnn_logits_log_softmax_bwd", ptr(d_logp), ptr(logp), ptr(hV), ptr(W), n_letters, N, ptr(d_hV), ptr(dW),
+             ptr(db), stream_ptr())
+        return d_hV, dW, db
+
+
+class SmoothedLossFn(torch.autograd.Function):
+    """loss_smoothed (reference train.py:63-73) in one launch: per-residue loss, the masked sum / 2000, and the gradient
+    of that sum, kept for backward."""
+
+    @staticmethod
+    def forward(ctx, log_probs, S, mask, weight):
+        n_letters = log_probs.shape[-1]
+        lp = log_probs.contiguous().float()
+        N = lp.numel() // n_letters
+        dev = lp.device
+        loss = torch.empty(S.shape, device=dev, dtype=torch.float32)
+        total = torch.zeros((), device=dev, dtype=torch.float32)
+        d_lp = torch.empty_like(lp)
+        call("mpnn_loss_smoothed", ptr(lp), ptr(S.contiguous()), ptr(mask.contiguous().float()), N, n_letters,
+             float(weight), 1.0 / 2000.0, ptr(loss), ptr(total), ptr(d_lp), stream_ptr())
+        ctx.save_for_backward(d_lp)
+        ctx.mark_non_differentiable(loss)
+        return loss, total
+
+    @staticmethod
+    def backward(ctx, _g_loss, g_total):
+        (d_lp,) = ctx.saved_tensors
+        return d_lp * g_total, None, None, None
+
+
+def loss_smoothed_fused(S, log_probs, mask, weight=0.1):
+    """`loss_smoothed` on the HIP kernel (same returns; the per-residue loss is not differentiable here, the scalar is)."""
+    return SmoothedLossFn.apply(log_probs, S, mask, weight)
 
 
 def loss_smoothed(S, log_probs, mask, weight=0.1):
@@ -582,7 +643,7 @@ def train_step(model, optimizer, batch, world_size=1, fix_order=None, fix_backbo
     optimizer.zero_grad(set_to_none=True)
     log_probs = forward_train(model, X, S, mask, chain_M, residue_idx, chain_enc, fix_order, fix_backbone_noise)
     mask_for_loss = mask * chain_M
-    _, loss = loss_smoothed(S, log_probs, mask_for_loss)
+    _, loss = loss_smoothed_fused(S, log_probs, mask_for_loss)
     loss.backward()
     distributed.allreduce_gradients(model.parameters(), world_size)  # no-op for a single rank
     if max_grad_norm and max_grad_norm > 0.0:

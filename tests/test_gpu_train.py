@@ -275,3 +275,36 @@ def test_eval_mode_with_grad_enabled_is_differentiable():
     loss_ref, _, want = oracle_loss_and_grads(model, kw, b)
     assert abs(loss.item() - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref))
     compare_grads({n: got.get(n, torch.zeros_like(v)) for n, v in want.items()}, want)
+
+
+@pytest.mark.parametrize("N,n_letters", [(1, 21), (70, 21), (1000, 21), (130, 7)])
+def test_head_backward_and_fused_loss_vs_aten(N, n_letters):
+    """mpnn_logits_log_softmax_bwd and mpnn_loss_smoothed (through their autograd wrappers) against the ATen ops the
+    reference uses (model_utils.py :527-528, train.py:63-73): values to 1e-5, gradients to 1e-5 relative."""
+    import torch.nn.functional as F
+
+    from mpnn_amd import training
+
+    g = torch.Generator().manual_seed(N)
+    hV = torch.randn(N, 128, generator=g).cuda().requires_grad_(True)
+    W = (0.2 * torch.randn(n_letters, 128, generator=g)).cuda().requires_grad_(True)
+    b = (0.1 * torch.randn(n_letters, generator=g)).cuda().requires_grad_(True)
+    S = torch.randint(0, n_letters, (N,), generator=g).cuda()
+    mask = (torch.rand(N, generator=g) < 0.8).float().cuda()
+
+    lp = training.HeadFn.apply(hV, W, b)
+    loss_vec, loss = training.loss_smoothed_fused(S, lp, mask)
+    loss.backward()
+    got = [t.grad.clone() for t in (hV, W, b)]
+    for t in (hV, W, b):
+        t.grad = None
+    lp_ref = F.log_softmax(F.linear(hV, W, b), dim=-1)
+    loss_vec_ref, loss_ref = training.loss_smoothed(S, lp_ref, mask)
+    loss_ref.backward()
+    want = [t.grad.clone() for t in (hV, W, b)]
+    assert (lp - lp_ref).abs().max().item() <= 1e-5   # fp32 summation order over the 128 features
+    assert (loss_vec - loss_vec_ref).abs().max().item() <= 1e-5
+    assert abs(loss.item() - loss_ref.item()) <= 1e-6 + 1e-5 * abs(loss_ref.item())
+    for name, a, r in zip(("d_hV", "dW", "db"), got, want):
+        err = (a - r).norm().item() / max(r.norm().item(), 1e-30)
+        assert err <= 1e-5, (name, err)
