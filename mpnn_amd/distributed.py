@@ -50,15 +50,18 @@ def allreduce_gradients(params, world: int, group=None):
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.div_(world)
-    off = 0
+    off, dst, src = 0, [], []
     for p in params:
         n = p.numel()
         g = flat[off:off + n].view_as(p)
         if p.grad is None:
             p.grad = g.clone()
         else:
-            p.grad.copy_(g)
+            dst.append(p.grad)
+            src.append(g)
         off += n
+    if dst:
+        torch._foreach_copy_(dst, src)  # one multi-tensor launch instead of one copy per parameter
 
 
 def broadcast_parameters(params, src: int = 0, group=None):
