@@ -82,7 +82,7 @@ __global__ void k_backbone_atoms(const float* __restrict__ X, const float* __res
 //   D      = m_i m_j sqrt(((dx^2 + dy^2) + dz^2) + 1e-6)
 //   D_adj  = D + (1 - m_i m_j) * rowmax(D)   [+ (1 - [cutoff > D]) * 1e6]
 //   output = K smallest D_adj ascending; equal values ordered by column index.
-// Selection: candidates stream through the wave 64 at a time as 64-bit keys
+// Selection: candidates pass through the wave 64 at a time as 64-bit keys
 // (float bits << 32 | column).  The running best-64 list lives one key per lane,
 // sorted; a chunk that cannot beat the current K-th key is skipped with one ballot,
 // otherwise it is bitonic-sorted (21 exchange stages) and bitonic-merged (7 stages).
@@ -133,39 +133,56 @@ k_knn_topk(const float* __restrict__ ca_soa, int B, int L, int K, int Kp, int ha
   const float *cy = cx + L, *cz = cx + 2 * L, *cm = cx + 3 * L;
   const float xi = cx[i], yi = cy[i], zi = cz[i], mi = cm[i];
 
-  // pass 1: row maximum of the masked distances
+  // Streaming selection over chunks of 64 candidates.  Chunks are visited outwards from the one that holds the query
+  // itself (c0, c0+1, c0-1, c0+2, ...): residues close in sequence are close in space, so the K-th best distance
+  // tightens within the first few chunks and most of the remaining ones are rejected by the ballot.  The result does
+  // not depend on the order: keys are totally ordered.
+  //
+  // Masked columns (m_i m_j != 1) take a value that depends on rowmax(D), which is only known after a full sweep.  The first
+  // sweep therefore leaves them out and computes rowmax on the way; they can only matter if rowmax <= the K-th best
+  // value found (short or padded-out proteins, masked query rows, cutoff penalties), and then a second sweep with the
+  // now known rowmax inserts them.  Fully valid proteins - the common case - make one sweep instead of two.
+  const int nchunks = (L + 63) >> 6, c0 = i >> 6;
   float dmax = 0.f;
-  for (int j0 = 0; j0 < L; j0 += 64) {
-    const int j = j0 + lane;
-    if (j < L) {
-      const float dx = cx[j] - xi, dy = cy[j] - yi, dz = cz[j] - zi;
-      const float d = (mi * cm[j]) * sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
-      dmax = fmaxf(dmax, d);
+  bool any_masked = false;
+  unsigned long long best = ~0ull;  // sorted ascending over lanes
+  auto sweep = [&](bool with_masked) {
+    best = ~0ull;
+    for (int t = 0; t < 2 * nchunks; ++t) {
+      const int cidx = (t & 1) ? c0 + ((t + 1) >> 1) : c0 - (t >> 1);
+      if (cidx < 0 || cidx >= nchunks) continue;
+      const int j = (cidx << 6) + lane;
+      unsigned long long key = ~0ull;
+      if (j < L) {
+        const float dx = cx[j] - xi, dy = cy[j] - yi, dz = cz[j] - zi;
+        const float m2 = mi * cm[j];
+        const float d = m2 * sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
+        if (!with_masked) {
+          dmax = fmaxf(dmax, d);
+          any_masked = any_masked || (m2 != 1.0f);
+        }
+        if (with_masked || m2 == 1.0f) {
+          float da = d + (1.0f - m2) * dmax;
+          if (has_cutoff) da = da + (1.0f - (cutoff > d ? 1.0f : 0.0f)) * 1e6f;
+          key = ((unsigned long long)__float_as_uint(da) << 32) | (unsigned)j;
+        }
+      }
+      const unsigned long long thr = shfl_u64(best, K - 1);
+      if (__ballot(key < thr) == 0ull) continue;
+      key = wave_sort64(key, lane);
+      const unsigned long long rev = shfl_u64(key, 63 - lane);
+      best = best < rev ? best : rev;  // bitonic: holds the 64 smallest of the union
+#pragma unroll
+      for (int jj = 32; jj > 0; jj >>= 1) best = cmpxchg(best, lane, jj, true);
     }
-  }
+  };
+  sweep(false);
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, m));
-
-  // pass 2: streaming selection
-  unsigned long long best = ~0ull;  // sorted ascending over lanes
-  for (int j0 = 0; j0 < L; j0 += 64) {
-    const int j = j0 + lane;
-    unsigned long long key = ~0ull;
-    if (j < L) {
-      const float dx = cx[j] - xi, dy = cy[j] - yi, dz = cz[j] - zi;
-      const float m2 = mi * cm[j];
-      const float d = m2 * sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
-      float da = d + (1.0f - m2) * dmax;
-      if (has_cutoff) da = da + (1.0f - (cutoff > d ? 1.0f : 0.0f)) * 1e6f;
-      key = ((unsigned long long)__float_as_uint(da) << 32) | (unsigned)j;
-    }
-    const unsigned long long thr = shfl_u64(best, K - 1);
-    if (__ballot(key < thr) == 0ull) continue;
-    key = wave_sort64(key, lane);
-    const unsigned long long rev = shfl_u64(key, 63 - lane);
-    best = best < rev ? best : rev;  // bitonic: holds the 64 smallest of the union
-#pragma unroll
-    for (int jj = 32; jj > 0; jj >>= 1) best = cmpxchg(best, lane, jj, true);
+  if (__ballot(any_masked) != 0ull) {
+    // value of a masked column: d = 0, so D_adj = rowmax (the cutoff term vanishes: cutoff > 0 = d)
+    const unsigned long long kth = shfl_u64(best, K - 1);
+    if (((unsigned long long)__float_as_uint(dmax) << 32) <= kth) sweep(true);
   }
   const float dsel = __uint_as_float((unsigned)(best >> 32));
   const int jsel = (int)(unsigned)(best & 0xffffffffu);
