@@ -445,6 +445,15 @@ def main():
                             "The kernel is VALU-issue bound (GELU + f16 splitting do not co-issue with MFMA here), "
                             "see DESIGN.md section 4"}
 
+    if roofline is None:
+        # tiny workloads can make a non-matrix kernel (node update, k-NN) the dominant one: price it against HBM
+        Kq = min(K, L)
+        nbytes = algorithmic_bytes(dominant, Kq, 16 * ((Kq + 15) // 16)) or 0
+        ach = nbytes * B * L / (dk["avg_ms"] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": traffic, "avg_launch_ms": round(dk["avg_ms"], 4),
+                    "note": "achieved = algorithmic bytes of the launch (DESIGN.md section 4.1) / HIP-event launch time"}
+
     # ---- secondary: reduced-precision forward (one f16 product per fp32 product), same workload and the L=4096 shape
     f16 = {}
     quiesce_gc()
