@@ -508,8 +508,10 @@ k_message_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, in
                 const float* __restrict__ b2, const int* __restrict__ node_list, int n_list, int enc_mod, int L, int K,
                 int KT, float* __restrict__ gsum) {
   __shared__ h8 lds[2 * WSPLIT];
+#ifndef MPNN_ABL_LEVEL_NOFILL  // timing-only ablation build: never shipped
   lds_fill(lds, W1b, WSPLIT);
   lds_fill(lds + WSPLIT, W2, WSPLIT);
+#endif
   __syncthreads();
   const h8* W1s = lds;
   const h8* W2s = lds + WSPLIT;
