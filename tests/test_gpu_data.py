@@ -72,3 +72,30 @@ def test_bad_ids_raise():
         shard.assemble([0, 4])
     with pytest.raises(IndexError):
         shard.assemble([])
+
+
+def test_training_over_assembled_batches_of_changing_shape():
+    """The loop the pieces are for: shard -> token-budget batches (different B and L every step) -> train_step with
+    the reference's recipe.  Finite decreasing-ish loss, finite weights, no shape-dependent state left behind."""
+    import mpnn_amd
+    from mpnn_amd import training
+    from mpnn_amd.synthetic import fill_parameters_
+
+    _, _, shard = build(40, seed=44)
+    model = mpnn_amd.ProteinMPNN(k_neighbors=32, augment_eps=0.1, dropout=0.1).train()
+    fill_parameters_(model, seed=0)
+    model = model.cuda()
+    batches = [b for b in TokenBudgetBatcher(shard.lengths, batch_size=1200, shuffle=False, drop_overflow=False).clusters]
+    assert len({(len(b), int(shard.lengths[b].max())) for b in batches}) >= 3
+    opt, sched = training.make_optimizer(model, lr=5e-4, total_steps=2 * len(batches))
+    first, last = [], []
+    for epoch in range(2):
+        for ids in batches:
+            X, S, mask, _, chain_M, ridx, _, chain_enc = shard.assemble(ids)
+            loss, lp = training.train_step(model, opt, (X, S, mask, chain_M, ridx, chain_enc), scheduler=sched,
+                                           max_grad_norm=1.0)
+            per_res = float(loss) * 2000.0 / max(float((mask * chain_M).sum()), 1.0)
+            (first if epoch == 0 else last).append(per_res)
+            assert np.isfinite(per_res) and lp.shape == (len(ids), X.shape[1], 21)
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    assert sum(last) / len(last) < sum(first) / len(first)
