@@ -168,6 +168,15 @@ class PackedWeights:
         return tuple((p.data_ptr(), p._version, str(p.device)) for p in model.parameters())
 
 
+def invalidate_packed(model):
+    """Drop every cached packed-weight set under `model`.  The cache key is (data_ptr, _version) per parameter, and
+    torch's FUSED optimizers update parameters without touching `_version` (measured: AdamW(fused=True) leaves it
+    unchanged), as does any edit through `.data`; the differentiable forward therefore calls this, so that whatever
+    optimizer follows it, the next inference call packs the new weights."""
+    for m in model.modules():
+        m.__dict__.pop("_packed", None)
+
+
 def packed(model) -> PackedWeights:
     pw = getattr(model, "_packed", None)
     if pw is None or pw.key != PackedWeights.make_key(model):

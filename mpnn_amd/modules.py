@@ -187,6 +187,12 @@ class ProteinMPNN(nn.Module):
         return engine.forward(self, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order,
                               fix_backbone_noise)
 
+    def refresh_weights(self):
+        """Forget the packed copies of the parameters the inference kernels cache.  Needed only after parameters were
+        changed behind autograd's back (`p.data` edits); optimizer steps and `load_state_dict` are covered."""
+        engine.invalidate_packed(self)
+        return self
+
     def sample(self, X, mask, chain_M, residue_idx, chain_encoding_all, S_true=None, n_samples=1, temperature=0.1,
                seed=0, fix_order=None, logit_bias=None):
         """Autoregressive sampling (no counterpart in the reference; see engine.sample)."""

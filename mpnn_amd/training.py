@@ -475,6 +475,7 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
     training = model.training
     p_drop = float(model.dropout_p) if training else 0.0
     _ZEROS.reset(dev)  # gradient accumulators of this step's backward pass
+    engine.invalidate_packed(model)  # an optimizer step follows: the inference kernels' packed weights go stale
     with torch.no_grad():
         atoms, _, E_idx64, E_idx32, _, edge_mask, K = engine._geometry(fm, X, mask, fix_backbone_noise, training)
         occ = engine._occupancy(fm, atoms, mask, B, L)
@@ -629,8 +630,12 @@ def make_optimizer(model, lr=1e-3, weight_decay=1e-2, total_steps=None):
     if total_steps is None:
         return optimizer, None
     warmup_steps = int(0.01 * total_steps)
-    warmup = LinearLR(optimizer, start_factor=1e-8, total_iters=warmup_steps)
     cosine = CosineAnnealingLR(optimizer, T_max=max(1, total_steps - warmup_steps), eta_min=0.0)
+    if warmup_steps == 0:
+        # fewer than 100 steps: the reference's SequentialLR would freeze the rate at lr * 1e-8 (a zero-length LinearLR
+        # never leaves its start factor); cosine only
+        return optimizer, cosine
+    warmup = LinearLR(optimizer, start_factor=1e-8, total_iters=warmup_steps)
     return optimizer, SequentialLR(optimizer, schedulers=[warmup, cosine], milestones=[warmup_steps])
 
 

@@ -308,3 +308,34 @@ def test_head_backward_and_fused_loss_vs_aten(N, n_letters):
     for name, a, r in zip(("d_hV", "dW", "db"), got, want):
         err = (a - r).norm().item() / max(r.norm().item(), 1e-30)
         assert err <= 1e-5, (name, err)
+
+
+def test_inference_sees_weights_updated_by_a_fused_optimizer():
+    """torch's fused AdamW does not bump Parameter._version, which keys the inference kernels' packed-weight cache:
+    after a training step the eval-mode forward must use the NEW weights (checked against the oracle on them)."""
+    from mpnn_amd import training
+    from mpnn_amd.synthetic import synthetic_batch
+
+    kw = dict(k_neighbors=30)
+    model = build(kw)
+    b = synthetic_batch(2, 64, seed=8, lengths=[64, 51], n_chains=2)
+    g = {k: v.cuda() for k, v in b.items()}
+    args = (g["X"], g["S"], g["mask"], g["chain_M"], g["residue_idx"], g["chain_encoding_all"])
+    model.eval()
+    with torch.no_grad():
+        before = model(*args, fix_order=g["fix_order"])       # fills the packed-weight cache
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, fused=True)
+    training.train_step(model, opt, args, fix_order=g["fix_order"])
+    model.eval()
+    with torch.no_grad():
+        after = model(*args, fix_order=g["fix_order"])
+    assert (after - before).abs().max().item() > 1e-3, "the step must be visible to the inference path"
+    from oracle import mpnn_oracle as orc
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = orc.forward(sd, oracle_cfg(kw), b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"],
+                          b["chain_encoding_all"], fix_order=b["fix_order"], formulation="edge")
+    m = b["mask"].bool()
+    err = (after.cpu() - ref).abs()[m]
+    assert bool((err <= 1e-5 + 1e-4 * ref.abs()[m]).all()), err.max().item()
