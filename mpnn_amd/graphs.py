@@ -31,8 +31,13 @@ class GraphedForward:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.out = model(*self.static[:6], fix_order=self.static[6])
+        # the graph reads the packed weights of THIS moment; keep them alive and notice when the model moves on
+        self._weights = model.__dict__.get("_packed")
 
     def __call__(self, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order):
+        if self.model.__dict__.get("_packed") is not self._weights:
+            raise RuntimeError("the model's weights were re-packed since the capture (training step, load_state_dict, "
+                               "refresh_weights): capture a new GraphedForward")
         for dst, src in zip(self.static, (X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order)):
             if dst.shape != src.shape:
                 raise ValueError(f"GraphedForward was captured for shape {tuple(dst.shape)}, got {tuple(src.shape)}")

@@ -105,6 +105,9 @@ def test_hip_graph_replay_is_bit_identical():
         with torch.no_grad():
             ref = model(*[b[k] for k in keys[:6]], fix_order=b["fix_order"])
         assert torch.equal(g(*[b[k] for k in keys]), ref)
+    model.refresh_weights()   # e.g. after a training step: the captured graph reads the old packed weights
+    with pytest.raises(RuntimeError):
+        g(*[b[k] for k in keys])
 
 
 @pytest.mark.parametrize("kw,B,L", [
