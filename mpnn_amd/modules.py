@@ -62,7 +62,8 @@ class EncLayer(nn.Module):
 
     def forward(self, h_V, h_E, E_idx, mask_V=None, mask_attend=None):
         """h_V [B,L,128], h_E [B,L,K,128], E_idx [B,L,K] -> (h_V, h_E), same layouts as the reference."""
-        return engine.enc_layer_standalone(self, h_V, h_E, E_idx, mask_V, mask_attend)
+        with torch.autocast(device_type="cuda", enabled=False):
+            return engine.enc_layer_standalone(self, h_V, h_E, E_idx, mask_V, mask_attend)
 
 
 class DecLayer(nn.Module):
@@ -84,7 +85,8 @@ class DecLayer(nn.Module):
 
     def forward(self, h_V, h_E, mask_V=None, mask_attend=None):
         """h_V [B,L,128], h_E = h_ESV [B,L,K,384] -> h_V, as the reference (:118-138)."""
-        return engine.dec_layer_standalone(self, h_V, h_E, mask_V, mask_attend)
+        with torch.autocast(device_type="cuda", enabled=False):
+            return engine.dec_layer_standalone(self, h_V, h_E, mask_V, mask_attend)
 
 
 class ProteinFeatures(nn.Module):
@@ -111,7 +113,8 @@ class ProteinFeatures(nn.Module):
 
     def forward(self, X, mask, residue_idx, chain_labels, backbone_noise=None):
         """-> (E [B,L,K,128], E_idx [B,L,K] int64, occupancy [B,L,1] | None, edge_mask [B,L,K] | None)."""
-        return engine.features_standalone(self, X, mask, residue_idx, chain_labels, backbone_noise)
+        with torch.autocast(device_type="cuda", enabled=False):
+            return engine.features_standalone(self, X, mask, residue_idx, chain_labels, backbone_noise)
 
 
 class ProteinMPNN(nn.Module):
@@ -172,6 +175,12 @@ class ProteinMPNN(nn.Module):
         times, energy_mpnn.py:42-62): X / mask / residue_idx / chain_encoding_all may be given with n < B rows (row r of
         S belongs to structure r % n) or as `expand`ed stride-0 views; in eval mode featurizer and encoder then run
         once per distinct structure.  The result equals the call on the materialised batch."""
+        # The kernels compute in fp32-class arithmetic whatever autocast says (>= the precision the reference's bf16
+        # autocast asks for, train.py:380-384); the ATen glue around them must not be re-typed under them.
+        with torch.autocast(device_type="cuda", enabled=False):
+            return self._forward(X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order, fix_backbone_noise)
+
+    def _forward(self, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order, fix_backbone_noise):
         # autograd semantics as for any nn.Module: with grad mode on and trainable parameters the differentiable path
         # runs (in eval mode too: no dropout, no backbone noise), inference callers use torch.no_grad()
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -196,5 +205,6 @@ class ProteinMPNN(nn.Module):
     def sample(self, X, mask, chain_M, residue_idx, chain_encoding_all, S_true=None, n_samples=1, temperature=0.1,
                seed=0, fix_order=None, logit_bias=None):
         """Autoregressive sampling (no counterpart in the reference; see engine.sample)."""
-        return engine.sample(self, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_samples, temperature,
-                             seed, fix_order, logit_bias)
+        with torch.autocast(device_type="cuda", enabled=False):
+            return engine.sample(self, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_samples,
+                                 temperature, seed, fix_order, logit_bias)

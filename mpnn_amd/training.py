@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import torch
 import torch.nn.functional as F
+from torch.amp import custom_bwd, custom_fwd  # backward runs under the forward's autocast state (off: modules.forward)
 
 from . import engine
 from . import _lib
@@ -152,12 +153,14 @@ class LinearFn(torch.autograd.Function):
     the library GEMM for this 'tiny output, 10^4-long reduction' shape takes 91 us per call."""
 
     @staticmethod
+    @custom_fwd(device_type="cuda")
     def forward(ctx, x, W, b):
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
         return F.linear(x, W, b)
 
     @staticmethod
+    @custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
@@ -190,6 +193,7 @@ class MessageFn(torch.autograd.Function):
     """gsum_i = sum_k w_ik gelu(W2 gelu(P_i + s_ik (Row_ik + W1b e_ik)) + b2)   (mpnn_edge.hip k_message)."""
 
     @staticmethod
+    @custom_fwd(device_type="cuda")
     def forward(ctx, g, slot, dec, hE, P, RowA, RowB, W1b, W2, b2):
         dev = hE.device
         P, RowA = P.contiguous(), RowA.contiguous()
@@ -211,6 +215,7 @@ class MessageFn(torch.autograd.Function):
         return gsum, cnt
 
     @staticmethod
+    @custom_bwd(device_type="cuda")
     def backward(ctx, dgsum, _dcnt):
         g, dec = ctx.g, ctx.dec
         hE, a1, a2, W1b, W2 = ctx.saved_tensors
@@ -239,6 +244,7 @@ class EdgeUpdateFn(torch.autograd.Function):
     """e' = LN3(e + W13 gelu(W12 gelu(P'_i + Q'_j + W11b e) + b12) + b13)   (mpnn_edge.hip k_enc_edge_update)."""
 
     @staticmethod
+    @custom_fwd(device_type="cuda")
     def forward(ctx, g, slot, p_drop, seed, hE, P, Q, W11b, W12, b12, W13, b13, lnw, lnb):
         dev = hE.device
         P, Q = P.contiguous(), Q.contiguous()
@@ -254,6 +260,7 @@ class EdgeUpdateFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         g = ctx.g
         hE, a1, a2, z, W11b, W12, W13, lnw = ctx.saved_tensors
@@ -281,11 +288,13 @@ class FromNaturalFn(torch.autograd.Function):
     """[N, K, 128] row-major edges -> fragment layout (and back for the gradient)."""
 
     @staticmethod
+    @custom_fwd(device_type="cuda")
     def forward(ctx, g, h_nat):
         ctx.g = g
         return engine.edges_from_natural(h_nat.contiguous(), g.N, g.K)
 
     @staticmethod
+    @custom_bwd(device_type="cuda")
     def backward(ctx, d_frag):
         g = ctx.g
         return None, engine.edges_to_natural(d_frag.contiguous(), g.N, g.K)
@@ -298,6 +307,7 @@ class FeaturesFn(torch.autograd.Function):
     """hE0 (fragment layout) from backbone atoms; parameters: embeddings.linear, edge_embedding, norm_edges, W_e."""
 
     @staticmethod
+    @custom_fwd(device_type="cuda")
     def forward(ctx, g, atoms, residue_idx, chain_labels, n_atoms, Wpos, bpos, Wemb, lnw, lnb, We, be):
         dev = atoms.device
         st = stream_ptr()
@@ -321,6 +331,7 @@ class FeaturesFn(torch.autograd.Function):
         return hE
 
     @staticmethod
+    @custom_bwd(device_type="cuda")
     def backward(ctx, dhE):
         g, na = ctx.g, ctx.n_atoms
         atoms, residue_idx, chain_labels, table, mu, E0, E, Wemb, lnw, We = ctx.saved_tensors
@@ -380,6 +391,7 @@ class NodeUpdateFn(torch.autograd.Function):
     projections Wproj_p h' + b_p   (reference :81-88, :127-137, :151-155; mpnn_node_bwd.hip)."""
 
     @staticmethod
+    @custom_fwd(device_type="cuda")
     def forward(ctx, meta, hV_in, gsum, cnt, mask, W3, b3, ln1w, ln1b, Win, bin_, Wout, bout, ln2w, ln2b, *projs):
         dev = hV_in.device
         N = hV_in.shape[0]
@@ -414,6 +426,7 @@ class NodeUpdateFn(torch.autograd.Function):
         return (hV_out,) + tuple(PQ[p] for p in range(nproj))
 
     @staticmethod
+    @custom_bwd(device_type="cuda")
     def backward(ctx, dY, *dPQ):
         scale, p_drop, seed = ctx.meta
         nproj = ctx.nproj
@@ -545,6 +558,7 @@ class HeadFn(torch.autograd.Function):
     backward (d_logits, d_hV, dW, db in one launch)."""
 
     @staticmethod
+    @custom_fwd(device_type="cuda")
     def forward(ctx, hV, W, bias):
         N, n_letters = hV.shape[0], W.shape[0]
         W = W.detach().float().contiguous()
@@ -560,6 +574,7 @@ class HeadFn(torch.autograd.Function):
         return logp
 
     @staticmethod
+    @custom_bwd(device_type="cuda")
     def backward(ctx, d_logp):
         hV, W, logp = ctx.saved_tensors
         N, n_letters = logp.shape
@@ -577,6 +592,7 @@ class SmoothedLossFn(torch.autograd.Function):
     of that sum, kept for backward."""
 
     @staticmethod
+    @custom_fwd(device_type="cuda")
     def forward(ctx, log_probs, S, mask, weight):
         n_letters = log_probs.shape[-1]
         lp = log_probs.contiguous().float()
@@ -592,6 +608,7 @@ class SmoothedLossFn(torch.autograd.Function):
         return loss, total
 
     @staticmethod
+    @custom_bwd(device_type="cuda")
     def backward(ctx, _g_loss, g_total):
         (d_lp,) = ctx.saved_tensors
         return d_lp * g_total, None, None, None

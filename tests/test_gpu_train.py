@@ -339,3 +339,36 @@ def test_inference_sees_weights_updated_by_a_fused_optimizer():
     m = b["mask"].bool()
     err = (after.cpu() - ref).abs()[m]
     assert bool((err <= 1e-5 + 1e-4 * ref.abs()[m]).all()), err.max().item()
+
+
+def test_autocast_context_does_not_retype_the_path():
+    """The reference's loop may wrap forward + loss in torch.autocast(bfloat16) (train.py:380-384) and nothing stops a
+    caller from running backward inside it too: outputs and gradients must be those of the plain call."""
+    from mpnn_amd import training
+    from mpnn_amd.synthetic import synthetic_batch
+
+    model = build(dict(k_neighbors=30))
+    b = synthetic_batch(2, 64, seed=4, lengths=[64, 50], n_chains=2)
+    g = {k: v.cuda() for k, v in b.items()}
+    args = (g["X"], g["S"], g["mask"], g["chain_M"], g["residue_idx"], g["chain_encoding_all"])
+
+    def run(autocast):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=autocast):
+            lp = model(*args, fix_order=g["fix_order"])
+            _, loss = training.loss_smoothed(g["S"], lp.float(), g["mask"] * g["chain_M"])
+            loss.backward()
+        return lp.detach(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    lp0, g0 = run(False)
+    lp1, g1 = run(True)
+    assert lp1.dtype == torch.float32 and torch.equal(lp0, lp1)
+    assert g0.keys() == g1.keys()
+    for n in g0:
+        assert torch.allclose(g0[n], g1[n], rtol=1e-5, atol=1e-10), n
+    model.eval()
+    with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        lp2 = model(*args, fix_order=g["fix_order"])
+    with torch.no_grad():
+        lp3 = model(*args, fix_order=g["fix_order"])
+    assert torch.equal(lp2, lp3)
