@@ -15,6 +15,14 @@ import torch.nn as nn
 from . import engine
 
 
+def _on_device_of(t):
+    """Kernels launch on the CURRENT device's stream: make the tensor's device current for the call (a model on cuda:1
+    called while cuda:0 is current would otherwise launch on the wrong GPU).  CPU tensors fall through to the
+    engine's own error."""
+    import contextlib
+    return torch.cuda.device(t.device) if isinstance(t, torch.Tensor) and t.is_cuda else contextlib.nullcontext()
+
+
 class PositionWiseFeedForward(nn.Module):
     """Parameters of the position-wise FFN (reference :141-155); evaluated inside mpnn_node_update."""
 
@@ -62,7 +70,7 @@ class EncLayer(nn.Module):
 
     def forward(self, h_V, h_E, E_idx, mask_V=None, mask_attend=None):
         """h_V [B,L,128], h_E [B,L,K,128], E_idx [B,L,K] -> (h_V, h_E), same layouts as the reference."""
-        with torch.autocast(device_type="cuda", enabled=False):
+        with _on_device_of(h_V), torch.autocast(device_type="cuda", enabled=False):
             return engine.enc_layer_standalone(self, h_V, h_E, E_idx, mask_V, mask_attend)
 
 
@@ -85,7 +93,7 @@ class DecLayer(nn.Module):
 
     def forward(self, h_V, h_E, mask_V=None, mask_attend=None):
         """h_V [B,L,128], h_E = h_ESV [B,L,K,384] -> h_V, as the reference (:118-138)."""
-        with torch.autocast(device_type="cuda", enabled=False):
+        with _on_device_of(h_V), torch.autocast(device_type="cuda", enabled=False):
             return engine.dec_layer_standalone(self, h_V, h_E, mask_V, mask_attend)
 
 
@@ -113,7 +121,7 @@ class ProteinFeatures(nn.Module):
 
     def forward(self, X, mask, residue_idx, chain_labels, backbone_noise=None):
         """-> (E [B,L,K,128], E_idx [B,L,K] int64, occupancy [B,L,1] | None, edge_mask [B,L,K] | None)."""
-        with torch.autocast(device_type="cuda", enabled=False):
+        with _on_device_of(X), torch.autocast(device_type="cuda", enabled=False):
             return engine.features_standalone(self, X, mask, residue_idx, chain_labels, backbone_noise)
 
 
@@ -177,7 +185,7 @@ class ProteinMPNN(nn.Module):
         once per distinct structure.  The result equals the call on the materialised batch."""
         # The kernels compute in fp32-class arithmetic whatever autocast says (>= the precision the reference's bf16
         # autocast asks for, train.py:380-384); the ATen glue around them must not be re-typed under them.
-        with torch.autocast(device_type="cuda", enabled=False):
+        with _on_device_of(X), torch.autocast(device_type="cuda", enabled=False):
             return self._forward(X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order, fix_backbone_noise)
 
     def _forward(self, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order, fix_backbone_noise):
@@ -205,6 +213,6 @@ class ProteinMPNN(nn.Module):
     def sample(self, X, mask, chain_M, residue_idx, chain_encoding_all, S_true=None, n_samples=1, temperature=0.1,
                seed=0, fix_order=None, logit_bias=None):
         """Autoregressive sampling (no counterpart in the reference; see engine.sample)."""
-        with torch.autocast(device_type="cuda", enabled=False):
+        with _on_device_of(X), torch.autocast(device_type="cuda", enabled=False):
             return engine.sample(self, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_samples,
                                  temperature, seed, fix_order, logit_bias)
