@@ -116,15 +116,15 @@ class StructureShard:
         residue_idx = torch.empty(B, L, device=dev, dtype=torch.int64)
         chain_enc = torch.empty(B, L, device=dev, dtype=torch.int64)
         lengths = torch.empty(B, device=dev, dtype=torch.int32)
-        torch.cuda.set_device(dev)  # launches go to the current device's stream
-        st = stream_ptr()
-        call("mpnn_assemble_batch", ptr(self.X), ptr(self.S), ptr(self.chain), ptr(self.designed), ptr(self.offsets),
-             ptr(ids_dev), B, L, ptr(X), ptr(S), ptr(mask), ptr(chain_M), ptr(residue_idx), ptr(chain_enc),
-             ptr(lengths), st)
         mask_self = None
-        if with_mask_self:
-            mask_self = torch.empty(B, L, L, device=dev, dtype=torch.float32)
-            call("mpnn_mask_self", ptr(chain_enc), B, L, ptr(mask_self), st)
+        with torch.cuda.device(dev):  # launches go to the current device's stream
+            st = stream_ptr()
+            call("mpnn_assemble_batch", ptr(self.X), ptr(self.S), ptr(self.chain), ptr(self.designed), ptr(self.offsets),
+                 ptr(ids_dev), B, L, ptr(X), ptr(S), ptr(mask), ptr(chain_M), ptr(residue_idx), ptr(chain_enc),
+                 ptr(lengths), st)
+            if with_mask_self:
+                mask_self = torch.empty(B, L, L, device=dev, dtype=torch.float32)
+                call("mpnn_mask_self", ptr(chain_enc), B, L, ptr(mask_self), st)
         return X, S, mask, lengths, chain_M, residue_idx, mask_self, chain_enc
 
 
