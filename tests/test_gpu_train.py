@@ -372,3 +372,45 @@ def test_autocast_context_does_not_retype_the_path():
     with torch.no_grad():
         lp3 = model(*args, fix_order=g["fix_order"])
     assert torch.equal(lp2, lp3)
+
+
+def test_energy_style_loss_gradients_vs_oracle():
+    """EnergyMPNN's use of the model (energy_mpnn.py:42-68, finetune loop): one structure repeated for B mutant
+    sequences, dG = sum(one_hot(S) * log_probs), a regression loss on dG - gradients of an arbitrary function of the
+    log-probs, not of loss_smoothed, against autograd through the oracle."""
+    import torch.nn.functional as F
+
+    from mpnn_amd.synthetic import synthetic_batch
+    from oracle import mpnn_oracle as orc
+
+    kw = dict(k_neighbors=32)
+    model = build(kw).eval()                      # fine-tuning without dropout / noise; grad mode is on
+    one = synthetic_batch(1, 60, seed=17, n_chains=2)
+    B = 4
+    gen = torch.Generator().manual_seed(3)
+    S = torch.randint(0, 21, (B, 60), generator=gen)
+    order = torch.argsort(torch.rand(B, 60, generator=gen), dim=-1)
+    target = torch.randn(B, generator=gen)
+    rep = {k: one[k].repeat(B, *([1] * (one[k].dim() - 1))) for k in ("X", "mask", "chain_M", "residue_idx",
+                                                                      "chain_encoding_all")}
+
+    def dG_loss(lp, S_):
+        dG = torch.sum(F.one_hot(S_, 21).float() * lp, dim=(1, 2))
+        return torch.mean((dG - target.to(lp.device)) ** 2)
+
+    model.zero_grad(set_to_none=True)
+    lp = model(X=rep["X"].cuda(), S=S.cuda(), mask=rep["mask"].cuda(), chain_M=rep["chain_M"].cuda(),
+               residue_idx=rep["residue_idx"].cuda(), chain_encoding_all=rep["chain_encoding_all"].cuda(),
+               fix_order=order.cuda())
+    loss = dG_loss(lp, S.cuda())
+    loss.backward()
+    got = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    lp_ref = orc.forward(sd, oracle_cfg(kw), rep["X"], S, rep["mask"], rep["chain_M"], rep["residue_idx"],
+                         rep["chain_encoding_all"], fix_order=order, formulation="edge")
+    loss_ref = dG_loss(lp_ref, S)
+    loss_ref.backward()
+    want = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items() if v.requires_grad}
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * max(1.0, abs(loss_ref.item()))
+    compare_grads({n: got.get(n, torch.zeros_like(v)) for n, v in want.items()}, want)
