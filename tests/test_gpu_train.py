@@ -364,8 +364,8 @@ def test_autocast_context_does_not_retype_the_path():
     lp1, g1 = run(True)
     assert lp1.dtype == torch.float32 and torch.equal(lp0, lp1)
     assert g0.keys() == g1.keys()
-    for n in g0:
-        assert torch.allclose(g0[n], g1[n], rtol=1e-5, atol=1e-10), n
+    for n in g0:  # the backward sums with fp32 atomics, so two runs agree to rounding, not bit for bit
+        assert (g0[n] - g1[n]).norm().item() <= 1e-5 * max(g0[n].norm().item(), 1e-12), n
     model.eval()
     with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.bfloat16):
         lp2 = model(*args, fix_order=g["fix_order"])
