@@ -13,7 +13,8 @@
  *   - return 0 on success; -1 for rejected arguments; otherwise the hipError_t of the launch.
  *     mpnn_last_error() returns a thread-local message.  No C++ exception crosses the ABI.
  *   - fp32 everywhere; hidden size is fixed at 128 (the reference's only used value), K <= 64.
- *   - "packed" weights are in the MFMA A-fragment layout produced by mpnn_pack_linear.
+ *   - "packed" weights are in the MFMA A-fragment layouts produced by mpnn_pack_linear_split (f16 hi/lo halves: every
+ *     128x128 matrix of the edge / node kernels) or mpnn_pack_linear (fp32: the two small heads).
  *   - "hE_frag" is the edge tensor in fragment layout [node][8][KT][64][4] floats, KT = ceil(K/16):
  *       hE_frag[n][t][c][lane][r] = h_E[n, 16c + (lane&15), 16t + 4(lane>>4) + r]
  *     (size n_nodes * 8 * KT * 256 floats).  Convert with mpnn_edges_to/from_natural.
