@@ -2,7 +2,8 @@
 
 Each case draws a model configuration (k, cutoff, occupancy, virtual centre, layer counts), a ragged multi-chain batch and
 a decoding order, and checks the HIP path against the oracle to the bars of tests/test_gpu_parity.py (indices and masks
-bit-exact, log-probs 1e-4 relative + 1e-5) and, for every third case, loss and gradients (relative L2 <= 1e-3).
+bit-exact, log-probs 1e-4 relative + 1e-5), for every third case loss and gradients (relative L2 <= 1e-3), and for
+every fourth case the sampler contract (a teacher-forced forward on the drawn sequences returns the sampler's log-probs).
 Prints one line per case and a summary; exit status 1 on any failure."""
 import os
 import sys
@@ -86,6 +87,27 @@ def main():
             if abs(loss.item() - loss_ref.item()) > 1e-5 * max(1.0, abs(loss_ref.item())) or worst > 1e-3:
                 msgs.append(f"training: loss {loss.item():.6g} vs {loss_ref.item():.6g}, worst gradient error {worst:.2e}")
             grad_note = f" grad {worst:.1e}"
+        if case % 4 == 1 and kw["k_neighbors"] <= 48 and m.any():
+            # sampler contract: the teacher-forced forward on the drawn sequences, same orders,
+            # returns the sampler's log-probs
+            model.eval()
+            ns = int(rng.integers(1, 4))
+            with torch.no_grad():
+                smp = model.sample(g["X"], g["mask"], g["chain_M"], g["residue_idx"], g["chain_encoding_all"],
+                                   S_true=g["S"], n_samples=ns, temperature=float(rng.choice([0.1, 1.0])),
+                                   seed=int(rng.integers(1 << 20)))
+                worst_s = 0.0
+                for q in range(ns):
+                    lp_tf = model(g["X"], smp["S"][q], g["mask"], g["chain_M"], g["residue_idx"],
+                                  g["chain_encoding_all"], fix_order=smp["order"][q])
+                    d = (lp_tf - smp["log_probs"][q]).abs()[g["mask"].bool()]
+                    worst_s = max(worst_s, float(d.max()) if d.numel() else 0.0)
+                fixed = (g["chain_M"] * g["mask"]) == 0
+                if not torch.equal(smp["S"][0][fixed], g["S"][fixed]):
+                    msgs.append("sampler changed a fixed residue")
+            if worst_s > 1e-4:
+                msgs.append(f"sampler vs teacher-forced forward: {worst_s:.2e}")
+            grad_note += f" sample {worst_s:.1e}"
         status = "ok" if not msgs else "FAIL " + "; ".join(msgs)
         bad += bool(msgs)
         print(f"case {case:3d} B={B} L={L:3d} lengths={lengths} {kw}: {status}"
