@@ -282,6 +282,18 @@ int mpnn_dec_message_subset(const float* hE_frag, const float* P, int ldp, int o
                             const float* W2_packed, const float* b2, const int32_t* node_list, int n_list,
                             int enc_nodes, int L, int K, float* gsum, void* stream);
 
+/* One decoder layer for the residues in node_list in a single launch: mpnn_dec_message_subset followed by
+ * mpnn_node_update_subset, with the neighbour sums kept in LDS (no gsum buffer).  A workgroup owns 16 listed residues. */
+int mpnn_dec_layer_subset(const float* hE_frag, const float* P, int ldp, int offP, const float* RowA, int lda, int offA,
+                          const float* PVenc, int ldenc, int offEnc, const int32_t* rank, const int32_t* E_idx32,
+                          const float* mask, const float* edge_mask, const float* W1b_packed, const float* W2_packed,
+                          const float* b2, const int32_t* node_list, int n_list, int enc_nodes, int L, int K,
+                          const float* hV_in, float cnt_const, const float* W3_packed, const float* b3,
+                          const float* ln1_w, const float* ln1_b, const float* Win_packed, const float* b_in,
+                          const float* Wout_packed, const float* b_out, const float* ln2_w, const float* ln2_b,
+                          float scale, const float* Wproj_packed, const float* bproj, int nproj, float* hV_out,
+                          float* PQ, void* stream);
+
 /* mpnn_node_update (do_update = 1, cnt = cnt_const, no table add) for the residues in node_list; sets the gsum rows it
  * has read back to zero, ready for the next level's accumulation. */
 int mpnn_node_update_subset(const float* hV_in, float* gsum, float cnt_const, const float* mask,
@@ -344,6 +356,16 @@ int mpnn_dec_message_subset_f16(const float* hE_frag, const float* P, int ldp, i
                             const int32_t* E_idx32, const float* mask, const float* edge_mask, const float* W1b_packed,
                             const float* W2_packed, const float* b2, const int32_t* node_list, int n_list,
                             int enc_nodes, int L, int K, float* gsum, void* stream);
+int mpnn_dec_layer_subset_f16(const float* hE_frag, const float* P, int ldp, int offP, const float* RowA, int lda,
+                              int offA, const float* PVenc, int ldenc, int offEnc, const int32_t* rank,
+                              const int32_t* E_idx32, const float* mask, const float* edge_mask,
+                              const float* W1b_packed, const float* W2_packed, const float* b2,
+                              const int32_t* node_list, int n_list, int enc_nodes, int L, int K, const float* hV_in,
+                              float cnt_const, const float* W3_packed, const float* b3, const float* ln1_w,
+                              const float* ln1_b, const float* Win_packed, const float* b_in,
+                              const float* Wout_packed, const float* b_out, const float* ln2_w, const float* ln2_b,
+                              float scale, const float* Wproj_packed, const float* bproj, int nproj, float* hV_out,
+                              float* PQ, void* stream);
 
 int mpnn_node_update_subset_f16(const float* hV_in, float* gsum, float cnt_const, const float* mask,
                             const float* W3_packed, const float* b3, const float* ln1_w, const float* ln1_b,

@@ -569,6 +569,171 @@ k_message_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, in
   }
 }
 
+// ---------------------------------------------------------------------------
+// One decoder layer for a dependency level in ONE launch: a workgroup (12 waves) owns a tile of LV_NODES listed residues,
+// computes their message tiles as k_message_level does - the neighbour sums meet in LDS instead of global
+// atomics - and then four of its waves run the node update on the tile (the wave split of k_node_update_level in
+// mpnn_node.hip: W3 by output-tile pairs, FFN by hidden quarters, projections by halves), with the exchange buffer
+// laid over the message weights that are no longer needed.  Saves a launch, the global gsum round trip and its
+// re-zeroing per layer and level.
+// ---------------------------------------------------------------------------
+#ifndef MPNN_LEVEL_RING
+#define MPNN_LEVEL_RING 8
+#endif
+// residues per workgroup: 4 x 3 column tiles = one message item per wave (items of one wave run one after the other,
+// each with its own chain of dependent loads, so more residues per workgroup only lengthen the launch)
+constexpr int LV_NODES = 4;
+__global__ void __launch_bounds__(MPNN_MSGT_WAVES * 64)
+k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp, int offP,
+                  const float* __restrict__ Abuf, int lda, int offA, const float* __restrict__ Bbuf, int ldb, int offB,
+                  const int* __restrict__ rank, const int* __restrict__ E_idx, const float* __restrict__ mask,
+                  const float* __restrict__ edge_mask, const h8* __restrict__ W1b, const h8* __restrict__ W2,
+                  const float* __restrict__ b2, const int* __restrict__ node_list, int n_list, int enc_mod, int L, int K,
+                  int KT, const float* __restrict__ hV_in, float cnt_const, const h8* __restrict__ W3,
+                  const float* __restrict__ b3, const float* __restrict__ ln1w, const float* __restrict__ ln1b,
+                  const h8* __restrict__ Win, const float* __restrict__ bin, const h8* __restrict__ Wout,
+                  const float* __restrict__ bout, const float* __restrict__ ln2w, const float* __restrict__ ln2b,
+                  float inv_scale, const h8* __restrict__ Wproj, const float* __restrict__ bproj, int nproj,
+                  float* __restrict__ hV_out, float* __restrict__ PQ) {
+  __shared__ h8 lds[2 * WSPLIT];
+  __shared__ float gsl[16][MPNN_H];
+  const h8* W1s = lds;
+  const h8* W2s = lds + WSPLIT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  const int Kp = KT * 16;
+  const int tile = blockIdx.x;
+  const int nlive = min(LV_NODES, n_list - tile * LV_NODES);
+  lds_fill(lds, W1b, WSPLIT);
+  lds_fill(lds + WSPLIT, W2, WSPLIT);
+  for (int i = threadIdx.x; i < 16 * MPNN_H; i += blockDim.x) (&gsl[0][0])[i] = 0.f;
+  __syncthreads();
+  // ---- message phase: item = (local residue, column tile)
+  for (int item = wave; item < nlive * KT; item += MPNN_MSGT_WAVES) {
+    LAUNDER(b2);
+    const int nl = item / KT, c = item % KT;
+    const int node = node_list[tile * LV_NODES + nl];
+    const int sh = node % enc_mod, b = node / L;
+    const int e = 16 * c + col;
+    const int jl = E_idx[(size_t)sh * Kp + e];
+    const int jn = b * L + jl;
+    float em = 1.0f;
+    if (edge_mask && e < K) em = edge_mask[(size_t)sh * K + e];
+    const bool before = rank[node] > rank[jn];
+    const float* row = before ? (Abuf + (size_t)jn * lda + offA + 4 * g)
+                              : (Bbuf + (size_t)((sh / L) * L + jl) * ldb + offB + 4 * g);
+    const float sc = mask[node] * em;
+    const float w = e < K ? 1.0f : 0.0f;
+    const float* Pi = Pbuf + (size_t)node * ldp + offP + 4 * g;
+    const f32x4* x = hE + ((size_t)sh * MPNN_NT * KT + c) * 64 + lane;
+    f32x4 xt[MPNN_NT], h1[MPNN_NT][1];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      xt[t] = x[(size_t)t * KT * 64];
+      h1[t][0] = row_tile(row, t);
+    }
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      BFrag bf[1];
+      split_pair(xt[2 * kk], xt[2 * kk + 1], bf[0]);
+      split_kstep<1, NKK, 0, MPNN_NT>(W1s, kk, lane, bf, h1);
+    }
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) h1[t][0] = h1[t][0] * sc + row_tile(Pi, t);
+    BFrag hb[NKK][1];
+    tile_to_bfrag<MPNN_NT, 1, true>(h1, hb);
+    f32x4 y[MPNN_NT][1];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) y[t][0] = *reinterpret_cast<const f32x4*>(b2 + 16 * t + 4 * g);
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) split_kstep<1, NKK, 0, MPNN_NT>(W2s, kk, lane, hb[kk], y);
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      f32x4 sm = gelu4(y[t][0]) * w;
+      sm.x = column_sum(sm.x); sm.y = column_sum(sm.y); sm.z = column_sum(sm.z); sm.w = column_sum(sm.w);
+      if (col == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&gsl[nl][16 * t + 4 * g + r], sm[r]);
+      }
+    }
+  }
+  __syncthreads();  // neighbour sums complete; the message weights in LDS are dead from here on
+  // ---- node phase: waves 0..3 work, the others only keep the barriers company
+  f32x4 (*ex)[MPNN_NT][64] = reinterpret_cast<f32x4 (*)[MPNN_NT][64]>(lds);
+  const bool act = wave < 4;
+  const int idx = tile * LV_NODES + col;
+  const bool live = col < LV_NODES && idx < n_list;
+  const int nd = node_list[live ? idx : n_list - 1];
+  f32x4 h[MPNN_NT][1], o[MPNN_NT][1];
+  BFrag xb[NKK][1];
+  if (act) {
+    f32x4 gs[MPNN_NT][1];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      h[t][0] = *reinterpret_cast<const f32x4*>(hV_in + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+      gs[t][0] = *reinterpret_cast<const f32x4*>(&gsl[col][16 * t + 4 * g]);
+    }
+    tile_to_bfrag<MPNN_NT, 1, false>(gs, xb);
+    f32x4 d2[2][1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) d2[i][0] = *reinterpret_cast<const f32x4*>(b3 + 16 * (2 * wave + i) + 4 * g) * cnt_const;
+    split_gemm_stream<1, NKK, 2, (MPNN_LEVEL_RING < 7 ? MPNN_LEVEL_RING : 7)>(W3 + (size_t)(2 * wave) * NKK * 2 * 64 + lane, xb, d2);
+    ex[0][2 * wave][lane] = d2[0][0];
+    ex[0][2 * wave + 1][lane] = d2[1][0];
+  }
+  __syncthreads();
+  if (act) {
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) h[t][0] += ex[0][t][lane] * inv_scale;
+    tile_layernorm<1>(h, ln1w, ln1b, lane);
+    tile_to_bfrag<MPNN_NT, 1, false>(h, xb);
+    f32x4 hid[MPNN_NT][1];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      hid[t][0] = *reinterpret_cast<const f32x4*>(bin + 128 * wave + 16 * t + 4 * g);
+      o[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    split_gemm_stream<1, NKK, MPNN_NT, MPNN_LEVEL_RING>(Win + (size_t)wave * WSPLIT + lane, xb, hid);
+    BFrag hb[NKK][1];
+    tile_to_bfrag<MPNN_NT, 1, true>(hid, hb);
+    split_gemm_stream<1, NKK, MPNN_NT, MPNN_LEVEL_RING>(Wout + (size_t)wave * WSPLIT + lane, hb, o);
+  }
+  __syncthreads();  // every wave has read the W3 exchange
+  if (act) {
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) ex[wave][t][lane] = o[t][0];
+  }
+  __syncthreads();
+  if (act) {
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+      o[t][0] = h[t][0] + *reinterpret_cast<const f32x4*>(bout + 16 * t + 4 * g) +
+                ((ex[0][t][lane] + ex[1][t][lane]) + (ex[2][t][lane] + ex[3][t][lane]));
+    tile_layernorm<1>(o, ln2w, ln2b, lane);
+    const float mk = mask[nd];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      h[t][0] = o[t][0] * mk;
+      if (live && wave == 0) *reinterpret_cast<f32x4*>(hV_out + (size_t)nd * MPNN_H + 16 * t + 4 * g) = h[t][0];
+    }
+    BFrag pb[NKK][1];
+    tile_to_bfrag<MPNN_NT, 1, false>(h, pb);
+    const int ld = nproj * MPNN_H;
+    for (int u = wave; u < 2 * nproj; u += 4) {
+      const int p = u >> 1, t0 = 4 * (u & 1);
+      f32x4 y[4][1];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[i][0] = *reinterpret_cast<const f32x4*>(bproj + p * MPNN_H + 16 * (t0 + i) + 4 * g);
+      split_gemm_stream<1, NKK, 4, (MPNN_LEVEL_RING < 15 ? MPNN_LEVEL_RING : 15)>(Wproj + (size_t)p * WSPLIT + (size_t)t0 * NKK * 2 * 64 + lane, pb, y);
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          *reinterpret_cast<f32x4*>(PQ + (size_t)nd * ld + p * MPNN_H + 16 * (t0 + i) + 4 * g) = y[i][0];
+      }
+    }
+  }
+}
+
 MPNN_KERNELS_END
 
 // ===========================================================================
@@ -733,5 +898,34 @@ extern "C" int MPNN_API(mpnn_dec_message_subset)(const float* hE_frag, const flo
   hipLaunchKernelGGL(k_message_level, grid, block, 0, (hipStream_t)stream, (const f32x4*)hE_frag, P, ldp, offP, RowA, lda,
                      offA, PVenc, ldenc, offEnc, rank, E_idx32, mask, edge_mask, (const h8*)W1b_packed,
                      (const h8*)W2_packed, b2, node_list, n_list, enc_nodes, L, K, KT, gsum);
+  MPNN_LAUNCH_CHECK();
+}
+
+// mpnn_dec_message_subset + mpnn_node_update_subset of one decoder layer in one launch (no gsum buffer)
+extern "C" int MPNN_API(mpnn_dec_layer_subset)(const float* hE_frag, const float* P, int ldp, int offP, const float* RowA,
+                                     int lda, int offA, const float* PVenc, int ldenc, int offEnc,
+                                     const int32_t* rank, const int32_t* E_idx32, const float* mask,
+                                     const float* edge_mask, const float* W1b_packed, const float* W2_packed,
+                                     const float* b2, const int32_t* node_list, int n_list, int enc_nodes, int L, int K,
+                                     const float* hV_in, float cnt_const, const float* W3_packed, const float* b3,
+                                     const float* ln1_w, const float* ln1_b, const float* Win_packed,
+                                     const float* b_in, const float* Wout_packed, const float* b_out,
+                                     const float* ln2_w, const float* ln2_b, float scale, const float* Wproj_packed,
+                                     const float* bproj, int nproj, float* hV_out, float* PQ, void* stream) {
+  MPNN_CHECK_ARG(hE_frag && P && RowA && PVenc && rank && E_idx32 && mask && W1b_packed && W2_packed && b2 &&
+                     node_list && hV_in && W3_packed && b3 && ln1_w && ln1_b && Win_packed && b_in && Wout_packed &&
+                     b_out && ln2_w && ln2_b && hV_out,
+                 "mpnn_dec_layer_subset: null pointer");
+  MPNN_CHECK_ARG(n_list > 0 && L > 0 && enc_nodes > 0 && enc_nodes % L == 0 && K >= 1 && K <= 48 && scale != 0.f &&
+                     nproj >= 0 && (nproj == 0 || (Wproj_packed && bproj && PQ)) &&
+                     mult4(ldp, offP, lda, offA, ldenc, offEnc),
+                 "mpnn_dec_layer_subset: bad sizes (K <= 48; strides/offsets multiples of 4 floats)");
+  const int KT = (K + 15) / 16;
+  hipLaunchKernelGGL(k_dec_layer_level, dim3(ceil_div(n_list, LV_NODES)), dim3(MPNN_MSGT_WAVES * 64), 0, (hipStream_t)stream,
+                     (const f32x4*)hE_frag, P, ldp, offP, RowA, lda, offA, PVenc, ldenc, offEnc, rank, E_idx32, mask,
+                     edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2, node_list, n_list, enc_nodes, L, K, KT,
+                     hV_in, cnt_const, (const h8*)W3_packed, b3, ln1_w, ln1_b, (const h8*)Win_packed, b_in,
+                     (const h8*)Wout_packed, b_out, ln2_w, ln2_b, 1.0f / scale, (const h8*)Wproj_packed, bproj, nproj,
+                     hV_out, PQ);
   MPNN_LAUNCH_CHECK();
 }

@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib
@@ -644,14 +646,19 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
                     ptr(lw["ln1b"]), ptr(lw["Win"]), ptr(lw["bin"]), ptr(lw["Wout"]), ptr(lw["bout"]), ptr(lw["ln2w"]),
                     ptr(lw["ln2b"]), lw["scale"], ptr(grp[0]), ptr(grp[1]), grp[2], None, 0, ptr(hVs[l + 1]),
                     ptr(PA[l + 1]) if grp[2] else None, st]
-            plans.append((msg, node))
+            # both in one launch (mpnn_dec_layer_subset): the message arguments without gsum, then the node update's
+            layer = msg[:22] + [node[0], node[2]] + node[4:18] + [node[20], node[21], st]
+            plans.append((msg, node, layer))
         head = [ptr(hVs[n_dec]), ptr(pw.Wlogit), ptr(pw.blogit), ptr(lb), pw.n_letters, None, 0, float(temperature),
                 int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(designable), ptr(S_in), ptr(S_out), ptr(log_probs), ptr(pw.TS),
                 pw.TS.shape[1], n_dec, A_rows, A_ld, A_off, st]
+        fused = os.environ.get("MPNN_SAMPLE_UNFUSED") != "1"  # one launch per decoder layer and level
+        f_layer = getattr(lib, _lib.entry("mpnn_dec_layer_subset"))
         f_msg = getattr(lib, _lib.entry("mpnn_dec_message_subset"))
         f_node = getattr(lib, _lib.entry("mpnn_node_update_subset"))
         f_head = lib.mpnn_sample_subset
         if _lib._profile is not None:  # bench.py's per-entry-point timing goes through the generic wrapper
+            f_layer = lambda *a: (call("mpnn_dec_layer_subset", *a), 0)[1]
             f_msg = lambda *a: (call("mpnn_dec_message_subset", *a), 0)[1]
             f_node = lambda *a: (call("mpnn_node_update_subset", *a), 0)[1]
             f_head = lambda *a: (call("mpnn_sample_subset", *a), 0)[1]
@@ -661,10 +668,14 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
         for cnt_l in counts:
             p_nodes = list_ptr + 4 * start
             start += cnt_l
-            for msg, node in plans:
-                msg[17], msg[18] = p_nodes, cnt_l
-                node[18], node[19] = p_nodes, cnt_l
-                rc = rc or f_msg(*msg) or f_node(*node)
+            for msg, node, layer in plans:
+                if fused:
+                    layer[17], layer[18] = p_nodes, cnt_l
+                    rc = rc or f_layer(*layer)
+                else:
+                    msg[17], msg[18] = p_nodes, cnt_l
+                    node[18], node[19] = p_nodes, cnt_l
+                    rc = rc or f_msg(*msg) or f_node(*node)
             head[5], head[6] = p_nodes, cnt_l
             rc = rc or f_head(*head)
         if rc:
