@@ -283,7 +283,8 @@ int mpnn_dec_message_subset(const float* hE_frag, const float* P, int ldp, int o
                             int enc_nodes, int L, int K, float* gsum, void* stream);
 
 /* One decoder layer for the residues in node_list in a single launch: mpnn_dec_message_subset followed by
- * mpnn_node_update_subset, with the neighbour sums kept in LDS (no gsum buffer).  A workgroup owns 16 listed residues. */
+ * mpnn_node_update_subset, with the neighbour sums kept in LDS (no gsum buffer).  A workgroup owns 4 listed residues.
+ * Wout_packed here is W_out as EIGHT 64-column blocks, each mpnn_pack_linear_split(W_out, col0 = 64 q, ncols = 64). */
 int mpnn_dec_layer_subset(const float* hE_frag, const float* P, int ldp, int offP, const float* RowA, int lda, int offA,
                           const float* PVenc, int ldenc, int offEnc, const int32_t* rank, const int32_t* E_idx32,
                           const float* mask, const float* edge_mask, const float* W1b_packed, const float* W2_packed,

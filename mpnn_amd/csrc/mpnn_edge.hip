@@ -572,8 +572,8 @@ k_message_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, in
 // ---------------------------------------------------------------------------
 // One decoder layer for a dependency level in ONE launch: a workgroup (12 waves) owns a tile of LV_NODES listed residues,
 // computes their message tiles as k_message_level does - the neighbour sums meet in LDS instead of global
-// atomics - and then four of its waves run the node update on the tile (the wave split of k_node_update_level in
-// mpnn_node.hip: W3 by output-tile pairs, FFN by hidden quarters, projections by halves), with the exchange buffer
+// atomics - and then eight of its waves run the node update on the tile (W3 by output tiles, FFN by hidden eighths,
+// projections by halves; cf. k_node_update_level in mpnn_node.hip), with the exchange buffer
 // laid over the message weights that are no longer needed.  Saves a launch, the global gsum round trip and its
 // re-zeroing per layer and level.
 // ---------------------------------------------------------------------------
@@ -658,9 +658,11 @@ k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, 
     }
   }
   __syncthreads();  // neighbour sums complete; the message weights in LDS are dead from here on
-  // ---- node phase: waves 0..3 work, the others only keep the barriers company
-  f32x4 (*ex)[MPNN_NT][64] = reinterpret_cast<f32x4 (*)[MPNN_NT][64]>(lds);
-  const bool act = wave < 4;
+  // ---- node phase on eight waves: W3 by output tile, the FFN by hidden eighths (64 units: four rows-tiles of W_in,
+  // one 64-column block of W_out, packed as eight [8][2] matrices by the host), projections by halves
+  constexpr int NODE_WAVES = 8;
+  f32x4 (*ex)[MPNN_NT][64] = reinterpret_cast<f32x4 (*)[MPNN_NT][64]>(lds);  // [NODE_WAVES][8][64] x 16 B = 64 KiB
+  const bool act = wave < NODE_WAVES;
   const int idx = tile * LV_NODES + col;
   const bool live = col < LV_NODES && idx < n_list;
   const int nd = node_list[live ? idx : n_list - 1];
@@ -674,12 +676,10 @@ k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, 
       gs[t][0] = *reinterpret_cast<const f32x4*>(&gsl[col][16 * t + 4 * g]);
     }
     tile_to_bfrag<MPNN_NT, 1, false>(gs, xb);
-    f32x4 d2[2][1];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) d2[i][0] = *reinterpret_cast<const f32x4*>(b3 + 16 * (2 * wave + i) + 4 * g) * cnt_const;
-    split_gemm_stream<1, NKK, 2, (MPNN_LEVEL_RING < 7 ? MPNN_LEVEL_RING : 7)>(W3 + (size_t)(2 * wave) * NKK * 2 * 64 + lane, xb, d2);
-    ex[0][2 * wave][lane] = d2[0][0];
-    ex[0][2 * wave + 1][lane] = d2[1][0];
+    f32x4 d1[1][1];
+    d1[0][0] = *reinterpret_cast<const f32x4*>(b3 + 16 * wave + 4 * g) * cnt_const;
+    split_gemm_stream<1, NKK, 1, 3>(W3 + (size_t)wave * NKK * 2 * 64 + lane, xb, d1);
+    ex[0][wave][lane] = d1[0][0];
   }
   __syncthreads();
   if (act) {
@@ -687,16 +687,15 @@ k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, 
     for (int t = 0; t < MPNN_NT; ++t) h[t][0] += ex[0][t][lane] * inv_scale;
     tile_layernorm<1>(h, ln1w, ln1b, lane);
     tile_to_bfrag<MPNN_NT, 1, false>(h, xb);
-    f32x4 hid[MPNN_NT][1];
+    f32x4 hid[4][1];
 #pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t) {
-      hid[t][0] = *reinterpret_cast<const f32x4*>(bin + 128 * wave + 16 * t + 4 * g);
-      o[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    split_gemm_stream<1, NKK, MPNN_NT, MPNN_LEVEL_RING>(Win + (size_t)wave * WSPLIT + lane, xb, hid);
-    BFrag hb[NKK][1];
-    tile_to_bfrag<MPNN_NT, 1, true>(hid, hb);
-    split_gemm_stream<1, NKK, MPNN_NT, MPNN_LEVEL_RING>(Wout + (size_t)wave * WSPLIT + lane, hb, o);
+    for (int t = 0; t < 4; ++t) hid[t][0] = *reinterpret_cast<const f32x4*>(bin + 64 * wave + 16 * t + 4 * g);
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) o[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    split_gemm_stream<1, NKK, 4, MPNN_LEVEL_RING>(Win + (size_t)(4 * wave) * NKK * 2 * 64 + lane, xb, hid);
+    BFrag hb[2][1];
+    tile_to_bfrag<4, 1, true>(hid, hb);
+    split_gemm_stream<1, 2, MPNN_NT, MPNN_LEVEL_RING>(Wout + (size_t)wave * (WSPLIT / 2) + lane, hb, o);
   }
   __syncthreads();  // every wave has read the W3 exchange
   if (act) {
@@ -706,9 +705,11 @@ k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, 
   __syncthreads();
   if (act) {
 #pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t)
-      o[t][0] = h[t][0] + *reinterpret_cast<const f32x4*>(bout + 16 * t + 4 * g) +
-                ((ex[0][t][lane] + ex[1][t][lane]) + (ex[2][t][lane] + ex[3][t][lane]));
+    for (int t = 0; t < MPNN_NT; ++t) {
+      f32x4 sum = (ex[0][t][lane] + ex[1][t][lane]) + (ex[2][t][lane] + ex[3][t][lane]);
+      sum += (ex[4][t][lane] + ex[5][t][lane]) + (ex[6][t][lane] + ex[7][t][lane]);
+      o[t][0] = h[t][0] + *reinterpret_cast<const f32x4*>(bout + 16 * t + 4 * g) + sum;
+    }
     tile_layernorm<1>(o, ln2w, ln2b, lane);
     const float mk = mask[nd];
 #pragma unroll
@@ -719,7 +720,7 @@ k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, 
     BFrag pb[NKK][1];
     tile_to_bfrag<MPNN_NT, 1, false>(h, pb);
     const int ld = nproj * MPNN_H;
-    for (int u = wave; u < 2 * nproj; u += 4) {
+    for (int u = wave; u < 2 * nproj; u += NODE_WAVES) {
       const int p = u >> 1, t0 = 4 * (u & 1);
       f32x4 y[4][1];
 #pragma unroll

@@ -119,6 +119,7 @@ class PackedWeights:
                      ln2b=vec(lyr.norm2.bias),
                      Win=pack_split(lyr.dense.W_in.weight), bin=vec(lyr.dense.W_in.bias),
                      Wout=torch.cat([pack_split(lyr.dense.W_out.weight, H * q, H) for q in range(4)]),
+                     Wout8=torch.cat([pack_split(lyr.dense.W_out.weight, 64 * q, 64) for q in range(8)]),
                      bout=vec(lyr.dense.W_out.bias), scale=float(lyr.scale))
             self.dec.append(d)
 
@@ -648,6 +649,7 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
                     ptr(PA[l + 1]) if grp[2] else None, st]
             # both in one launch (mpnn_dec_layer_subset): the message arguments without gsum, then the node update's
             layer = msg[:22] + [node[0], node[2]] + node[4:18] + [node[20], node[21], st]
+            layer[30] = ptr(lw["Wout8"])  # the fused kernel splits the FFN over eight waves: W_out in 64-column blocks
             plans.append((msg, node, layer))
         head = [ptr(hVs[n_dec]), ptr(pw.Wlogit), ptr(pw.blogit), ptr(lb), pw.n_letters, None, 0, float(temperature),
                 int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(designable), ptr(S_in), ptr(S_out), ptr(log_probs), ptr(pw.TS),
