@@ -3,7 +3,8 @@
 Each case draws a model configuration (k, cutoff, occupancy, virtual centre, layer counts), a ragged multi-chain batch and
 a decoding order, and checks the HIP path against the oracle to the bars of tests/test_gpu_parity.py (indices and masks
 bit-exact, log-probs 1e-4 relative + 1e-5), for every third case loss and gradients (relative L2 <= 1e-3), and for
-every fourth case the sampler contract (a teacher-forced forward on the drawn sequences returns the sampler's log-probs).
+every fourth case the sampler contract (a teacher-forced forward on the drawn sequences returns the sampler's log-probs);
+every fifth case the f16-product mode (max |d log p| <= 5e-2), every seventh the shared-structure forward (bit-identical).
 Prints one line per case and a summary; exit status 1 on any failure."""
 import os
 import sys
@@ -108,6 +109,30 @@ def main():
             if worst_s > 1e-4:
                 msgs.append(f"sampler vs teacher-forced forward: {worst_s:.2e}")
             grad_note += f" sample {worst_s:.1e}"
+        if case % 5 == 2 and m.any():
+            # reduced-precision forward (one f16 product): bar of include/mpnn_hip.h, max |d log p| <= 5e-2
+            model.eval()
+            model.set_precision("f16")
+            with torch.no_grad():
+                fast = model(*args, fix_order=g["fix_order"])
+            model.set_precision("fp32")
+            d16 = float((fast.cpu() - out["log_probs"].cpu()).abs()[m].max())
+            if d16 > 5e-2:
+                msgs.append(f"f16 products: {d16:.2e}")
+            grad_note += f" f16 {d16:.1e}"
+        if case % 7 == 3 and kw["k_neighbors"] <= 48:
+            # shared-structure forward: three sequences on structure 0, given once vs repeated - bit-identical
+            model.eval()
+            S3 = torch.randint(0, 21, (3, L), generator=torch.Generator().manual_seed(case)).cuda()
+            o3 = torch.argsort(torch.rand(3, L, generator=torch.Generator().manual_seed(case + 1)), dim=-1).cuda()
+            side = [t[:1] for t in (g["X"], g["mask"], g["residue_idx"], g["chain_encoding_all"])]
+            with torch.no_grad():
+                a3 = model(side[0], S3, side[1], g["chain_M"][:1], side[2], side[3], fix_order=o3)
+                b3 = model(side[0].repeat(3, 1, 1, 1), S3, side[1].repeat(3, 1), g["chain_M"][:1].repeat(3, 1),
+                           side[2].repeat(3, 1), side[3].repeat(3, 1), fix_order=o3)
+            if not torch.equal(a3, b3):
+                msgs.append("shared-structure forward differs from the repeated batch")
+            grad_note += " shared ok"
         status = "ok" if not msgs else "FAIL " + "; ".join(msgs)
         bad += bool(msgs)
         print(f"case {case:3d} B={B} L={L:3d} lengths={lengths} {kw}: {status}"
