@@ -297,6 +297,31 @@ def sampling_leg(a, dev, rank, world, dist, barrier):
                                    f"({mine} on rank 0), temperature 0.1", "dependency_levels": out["n_levels"]}}
 
 
+def self_launch(n, json_fd):
+    """`python bench.py --gpus N` without a launcher: run the same command line under torch.distributed.run with N
+    local ranks (RCCL by default, BENCH_BACKEND=gloo to rehearse on fewer GPUs).  Nothing in this parent process has
+    initialised the GPU.  Returns the exit code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        print(f"bench.py: the {n}-rank run failed (exit code {p.returncode}, {len(lines)} JSON lines)", file=sys.stderr)
+        return p.returncode or 1
+    os.write(json_fd, (lines[-1] + "\n").encode())
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -319,13 +344,18 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # started as plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU under
+        # torch.distributed.run) BEFORE this process touches the GPU, relay rank 0's JSON line, fail if any rank fails
+        sys.exit(self_launch(a.gpus, json_fd))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            print(f"bench.py: --gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: start {a.gpus} ranks (or run `python bench.py --gpus "
+              f"{a.gpus}` without a launcher, which starts them itself)", file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no ROCm device visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
@@ -524,6 +554,10 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: synthetic backbones, batch {B} x L={L}, k={K}, hidden 128, "
                                    "3 enc + 3 dec layers, fp32 forward + teacher-forced decoder",
                        "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world} (proteins sharded, no collective)"},
+            "ranks": {"world_size": dist.get_world_size() if dist is not None else 1,
+                      "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else ""))
+                      if dist is not None else "none (single process)"},
+            "rccl_ranks": dist.get_world_size() if (dist is not None and dist.get_backend() == "nccl") else 0,
             "whole_forward_tflops_as_written": round(FLOP_FWD_PER_RES * value / 1e12, 2),
             "roofline": roofline,
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(per_kernel.items())},

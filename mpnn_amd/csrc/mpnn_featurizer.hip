@@ -473,8 +473,12 @@ k_decode_levels(const long long* __restrict__ order, const int* __restrict__ ran
   const int row = blockIdx.x, p = row % enc_rows, lane = threadIdx.x;
   const long long* ord = order + (size_t)row * L;
   const int* rk = rank + (size_t)row * L;
+  for (int t = lane; t < L; t += 64) lv[t] = 0;
+  __builtin_amdgcn_wave_barrier();
   for (int t = 0; t < L; ++t) {
-    const int i = (int)ord[t];
+    const long long iq = ord[t];
+    if (iq < 0 || iq >= L) continue;  // not a permutation (the host wrapper rejects it): stay in bounds regardless
+    const int i = (int)iq;
     int m = 0;
     if (lane < K) {
       const int j = E_idx[((size_t)p * L + i) * Kp + lane];
@@ -486,6 +490,10 @@ k_decode_levels(const long long* __restrict__ order, const int* __restrict__ ran
       lv[i] = m + 1;
       level[(size_t)row * L + i] = m + 1;
     }
+    // lane 0's LDS store must be visible to the other lanes' loads of the next iteration
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 

@@ -7,6 +7,12 @@ that host work is the bottleneck of the loop.  Here the entries are flattened ON
 per-residue tensors + offsets) that lives in HBM, and a batch is one kernel launch (`mpnn_assemble_batch`) that writes
 the same eight outputs `featurize` returns, in the dtypes the model takes.
 
+Difference from the reference (documented, not hidden): `featurize` reshuffles the chain order of every entry on EVERY
+batch (data_utils.py:88), so `residue_idx` offsets and chain numbers change from epoch to epoch; a `StructureShard`
+fixes the chain order once, when it is built (`flatten_entry`).  To keep that augmentation rebuild the shard per epoch
+(`StructureShard.from_entries(entries, rng)`, host work of a few ms per thousand entries) - `assemble` itself never
+permutes chains.
+
 Host code in this file is plumbing (numpy over Python dicts, executed once per dataset); the per-batch path is the HIP
 kernel and has no CPU fallback.
 """

@@ -321,8 +321,13 @@ def forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_ord
                                                                                chain_encoding_all)
         B = S.shape[0]
         if n_struct != B:
+            # per-ROW backbone noise (B rows on n < B structures) makes every row its own structure: the shared path
+            # applies only when the noise is absent or given per structure (reference adds it per row, :311-312)
+            noise_rows = None if fix_backbone_noise is None else fix_backbone_noise.shape[0]
+            if noise_rows == B and B > 1 and fix_backbone_noise.stride(0) == 0:
+                fix_backbone_noise, noise_rows = fix_backbone_noise[:1].expand(n_struct, *fix_backbone_noise.shape[1:]), n_struct
             if (not model.training and not return_intermediates and model.features.top_k <= 48
-                    and len(model.decoder_layers) > 0):
+                    and len(model.decoder_layers) > 0 and noise_rows in (None, n_struct)):
                 return _forward_shared(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order,
                                        fix_backbone_noise)
             X, mask, residue_idx, chain_encoding_all = (_tile_rows(t, B) for t in
@@ -607,6 +612,12 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
         cm = (_f32(chain_M) * mask)
         if fix_order is not None:
             order = _i64(fix_order)
+            if order.shape[-2:] != (B, L) or (order.dim() == 3 and order.shape[0] != n_samples):
+                raise ValueError(f"fix_order must be [B, L] or [n_samples, B, L] = [{n_samples}, {B}, {L}], "
+                                 f"got {tuple(order.shape)}")
+            # the level scheduler indexes with the order: it must be a permutation of 0..L-1 per row
+            if not bool((torch.sort(order, dim=-1).values == torch.arange(L, device=dev)).all()):
+                raise ValueError("fix_order: every row must be a permutation of 0..L-1")
             order = order.expand(n_samples, B, L).contiguous() if order.dim() == 2 else order.contiguous()
         else:  # reference :489-491, one draw per sample
             g_ = torch.Generator(device=dev)

@@ -35,9 +35,15 @@ class GraphedForward:
         self._weights = model.__dict__.get("_packed")
 
     def __call__(self, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order):
-        if self.model.__dict__.get("_packed") is not self._weights:
-            raise RuntimeError("the model's weights were re-packed since the capture (training step, load_state_dict, "
-                               "refresh_weights): capture a new GraphedForward")
+        from .engine import PackedWeights
+
+        # stale when the packed set was replaced (eager forward after a change, refresh_weights, training step) OR when
+        # any parameter changed since the capture without a re-pack yet (load_state_dict, in-place copy_, a non-fused
+        # optimizer step): the key is (data_ptr, _version, device) per parameter, taken when the weights were packed
+        if (self._weights is None or self.model.__dict__.get("_packed") is not self._weights
+                or PackedWeights.make_key(self.model) != self._weights.key):
+            raise RuntimeError("the model's weights changed or were re-packed since the capture (training step, "
+                               "load_state_dict, in-place update, refresh_weights): capture a new GraphedForward")
         for dst, src in zip(self.static, (X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order)):
             if dst.shape != src.shape:
                 raise ValueError(f"GraphedForward was captured for shape {tuple(dst.shape)}, got {tuple(src.shape)}")

@@ -180,7 +180,9 @@ def linear(x, W, b=None):
 
 class GradSlot:
     """Shared gradient buffer of one edge tensor hE_l.  Its consumers' backward kernels accumulate in place; the first
-    one hands the buffer to autograd, the others return None (autograd runs the producer only after all of them)."""
+    one hands the buffer to autograd, the others return None (autograd runs the producer only after all of them).
+    The producer's backward (EdgeUpdateFn / FeaturesFn, `out_slot`) clears the slot again, so a second backward over
+    the same graph (retain_graph=True, two losses on one forward) starts from a fresh buffer."""
 
     def __init__(self):
         self.buf = None
@@ -245,7 +247,7 @@ class EdgeUpdateFn(torch.autograd.Function):
 
     @staticmethod
     @custom_fwd(device_type="cuda")
-    def forward(ctx, g, slot, p_drop, seed, hE, P, Q, W11b, W12, b12, W13, b13, lnw, lnb):
+    def forward(ctx, g, slot, out_slot, p_drop, seed, hE, P, Q, W11b, W12, b12, W13, b13, lnw, lnb):
         dev = hE.device
         P, Q = P.contiguous(), Q.contiguous()
         out = torch.empty_like(hE)
@@ -255,7 +257,7 @@ class EdgeUpdateFn(torch.autograd.Function):
         call("mpnn_enc_edge_update_train", ptr(hE), ptr(P), ptr(Q), ptr(g.E_idx32), ptr(w1p),
              ptr(w2p), ptr(vec[0]), ptr(w3p), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), g.B, g.L,
              g.K, ptr(out), ptr(a1), ptr(a2), ptr(z), float(p_drop), int(seed), stream_ptr())
-        ctx.g, ctx.slot, ctx.drop = g, slot, (float(p_drop), int(seed))
+        ctx.g, ctx.slot, ctx.out_slot, ctx.drop = g, slot, out_slot, (float(p_drop), int(seed))
         ctx.save_for_backward(hE, a1, a2, z, W11b, W12, W13, lnw)
         return out
 
@@ -266,6 +268,7 @@ class EdgeUpdateFn(torch.autograd.Function):
         hE, a1, a2, z, W11b, W12, W13, lnw = ctx.saved_tensors
         dev = hE.device
         dy = dy.contiguous()
+        ctx.out_slot.buf = None  # every consumer of this kernel's output has run: its gradient buffer is spent
         assert ctx.slot.buf is None, "the edge update is the first consumer of its input to run backward"
         dz, da2, dE = torch.empty_like(hE), torch.empty_like(hE), torch.empty_like(hE)
         ctx.slot.buf = dE
@@ -281,7 +284,7 @@ class EdgeUpdateFn(torch.autograd.Function):
         dW13, db13 = _wgrad(dz, False, amax[0:1], a2, True, g, True)
         dW12, db12 = _wgrad(da2, False, amax[1:2], a1, True, g, True)
         dW11b, _ = _wgrad(rows, True, amax[2:3], hE, False, g, False)
-        return None, None, None, None, dE, dP, dQ, dW11b, dW12, db12, dW13, db13, dln[:H], dln[H:]
+        return None, None, None, None, None, dE, dP, dQ, dW11b, dW12, db12, dW13, db13, dln[:H], dln[H:]
 
 
 class FromNaturalFn(torch.autograd.Function):
@@ -308,7 +311,7 @@ class FeaturesFn(torch.autograd.Function):
 
     @staticmethod
     @custom_fwd(device_type="cuda")
-    def forward(ctx, g, atoms, residue_idx, chain_labels, n_atoms, Wpos, bpos, Wemb, lnw, lnb, We, be):
+    def forward(ctx, g, out_slot, atoms, residue_idx, chain_labels, n_atoms, Wpos, bpos, Wemb, lnw, lnb, We, be):
         dev = atoms.device
         st = stream_ptr()
         table = torch.empty(66 * 16, device=dev, dtype=torch.float32)
@@ -326,7 +329,7 @@ class FeaturesFn(torch.autograd.Function):
         call("mpnn_edge_features_train", ptr(atoms), ptr(g.E_idx32), ptr(residue_idx), ptr(chain_labels), ptr(table),
              ptr(mu), ptr(Wemb_p), ptr(vec[0]), ptr(vec[1]), ptr(We_p), ptr(vec[2]), g.B, g.L, g.K, n_atoms, ptr(E0),
              ptr(E), ptr(hE), st)
-        ctx.g, ctx.n_atoms = g, n_atoms
+        ctx.g, ctx.n_atoms, ctx.out_slot = g, n_atoms, out_slot
         ctx.save_for_backward(atoms, residue_idx, chain_labels, table, mu, E0, E, Wemb, lnw, We)
         return hE
 
@@ -334,6 +337,7 @@ class FeaturesFn(torch.autograd.Function):
     @custom_bwd(device_type="cuda")
     def backward(ctx, dhE):
         g, na = ctx.g, ctx.n_atoms
+        ctx.out_slot.buf = None  # every consumer of hE0 has run
         atoms, residue_idx, chain_labels, table, mu, E0, E, Wemb, lnw, We = ctx.saved_tensors
         dev = dhE.device
         st = stream_ptr()
@@ -358,7 +362,7 @@ class FeaturesFn(torch.autograd.Function):
         npos = W.shape[1] - nrbf
         dT = G.t() @ W[:, :npos]                                            # gradient of the 66 x 16 embedding table
         dWemb = torch.cat([G @ table.view(66, 16), dF[:, :nrbf]], dim=1)
-        return (None, None, None, None, None, dT.t().contiguous(), dT.sum(0), dWemb, dln[:H], dln[H:], dWe, dbe)
+        return (None, None, None, None, None, None, dT.t().contiguous(), dT.sum(0), dWemb, dln[:H], dln[H:], dWe, dbe)
 
 
 def _node_wgrad(dy, x, want_bias):
@@ -496,10 +500,10 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
     if K > 48:
         raise NotImplementedError("mpnn_amd's differentiable path covers k_neighbors <= 48; for inference with more "
                                   "neighbours call the model under torch.no_grad()")
-    hE = FeaturesFn.apply(g, atoms, residue_idx, chain_labels, 6 if fm.use_virtual_center else 5,
+    slot = GradSlot()
+    hE = FeaturesFn.apply(g, slot, atoms, residue_idx, chain_labels, 6 if fm.use_virtual_center else 5,
                           fm.embeddings.linear.weight, fm.embeddings.linear.bias, fm.edge_embedding.weight,
                           fm.norm_edges.weight, fm.norm_edges.bias, model.W_e.weight, model.W_e.bias)
-    slot = GradSlot()
     hV = torch.zeros(N, H, device=dev, dtype=torch.float32)
     if model.occupancy_mlp is not None and occ is not None:
         hV = hV + model.occupancy_mlp(occ.view(N, 1))
@@ -524,9 +528,11 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
         hV, proj = _node_update(lyr, hV, gsum, cnt, g.mask, p_drop,
                                 [(W11[:, :H], lyr.W11.bias), (W11[:, 2 * H:3 * H], None)] + nxt)
         drop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
-        hE = EdgeUpdateFn.apply(g, slot, p_drop, drop_seed, hE, proj[0], proj[1], W11[:, H:2 * H], lyr.W12.weight,
-                                lyr.W12.bias, lyr.W13.weight, lyr.W13.bias, lyr.norm3.weight, lyr.norm3.bias)
-        slot = GradSlot()
+        out_slot = GradSlot()
+        hE = EdgeUpdateFn.apply(g, slot, out_slot, p_drop, drop_seed, hE, proj[0], proj[1], W11[:, H:2 * H],
+                                lyr.W12.weight, lyr.W12.bias, lyr.W13.weight, lyr.W13.bias, lyr.norm3.weight,
+                                lyr.norm3.bias)
+        slot = out_slot
         proj = proj[2:]
 
     if dec:

@@ -36,3 +36,21 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert c["kind"] in ("port", "reference") and c["value"] > 0
     for leg in ("train_step", "sampling", "shared_structure", "batch_assembly", "kernel_rooflines"):
         assert leg in d, leg
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torch.distributed.run: bench.py starts the two ranks itself.  On a one-GPU box
+    both ranks share the card and the collectives go over gloo (BENCH_BACKEND=gloo); the driver's 8-GPU run uses RCCL."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--length", "96", "--train-batch", "2", "--samples", "4", "--no-f16-leg"]
+    env = dict(os.environ, BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"]["world_size"] == 2 and d["ranks"]["backend"] == "gloo"
+    assert d["rccl_ranks"] == 0 and d["config"]["global_batch"] == 4
+    assert abs(d["value"] - 2 * 2 * 96 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-2   # whole-job residues/s
+    assert d["train_step"]["n_gpus"] == 2 and d["sampling"]["n_gpus"] == 2

@@ -108,6 +108,19 @@ def test_hip_graph_replay_is_bit_identical():
     model.refresh_weights()   # e.g. after a training step: the captured graph reads the old packed weights
     with pytest.raises(RuntimeError):
         g(*[b[k] for k in keys])
+    # a parameter change WITHOUT an eager forward in between (load_state_dict / in-place copy_): the packed set still
+    # has its old identity, the replay must notice through the parameter versions
+    g2 = GraphedForward(model, *[b1[k] for k in keys])
+    g2(*[b2[k] for k in keys])
+    sd = {k: v.clone() * 1.01 for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    with pytest.raises(RuntimeError):
+        g2(*[b2[k] for k in keys])
+    g3 = GraphedForward(model, *[b1[k] for k in keys])
+    with torch.no_grad():
+        model.W_out.bias.add_(0.5)
+    with pytest.raises(RuntimeError):
+        g3(*[b2[k] for k in keys])
 
 
 @pytest.mark.parametrize("kw,B,L", [

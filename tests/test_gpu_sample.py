@@ -51,6 +51,61 @@ def test_sampler_matches_teacher_forced_forward(name):
     print(f"{name}: {out['n_levels']} dependency levels for L={S.shape[-1]}")
 
 
+def _oracle_log_probs(model, kw, b, S, order):
+    """Teacher-forced forward of the CPU oracle (reference model_utils.py:427-529 with fix_order) on one sample."""
+    from conftest import oracle_cfg
+    from oracle import mpnn_oracle as orc
+
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        return orc.forward(sd, oracle_cfg(kw), b["X"], S.cpu(), b["mask"], b["chain_M"], b["residue_idx"],
+                           b["chain_encoding_all"], fix_order=order.cpu(), formulation="edge")
+
+
+def _assert_lp_close(lp, ref, what):
+    err = (lp.cpu().double() - ref.double()).abs()
+    tol = 1e-5 + 1e-4 * ref.double().abs()   # the forward's bar (SURVEY 8d): 1e-4 relative + 1e-5 absolute
+    assert bool((err <= tol).all()), f"{what}: max |d log p| {float(err.max()):.3e} vs the oracle"
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_sampler_matches_oracle(name):
+    """SURVEY 8 A14's contract against the ORACLE (not the HIP forward): the reference's teacher-forced forward on the
+    sampled sequence with the sampler's decoding order returns the log-probs the sampler drew from."""
+    from mpnn_amd.synthetic import synthetic_batch
+
+    kw, bkw, n_samples = CASES[name]
+    model = build(kw)
+    b = synthetic_batch(**bkw)
+    g = {k: v.to("cuda") for k, v in b.items()}
+    out = model.sample(g["X"], g["mask"], g["chain_M"], g["residue_idx"], g["chain_encoding_all"], S_true=g["S"],
+                       n_samples=n_samples, temperature=0.5, seed=11)
+    for s in range(n_samples):
+        ref = _oracle_log_probs(model, kw, b, out["S"][s], out["order"][s])
+        _assert_lp_close(out["log_probs"][s], ref, f"{name} sample {s}")
+
+
+def test_sampler_configs4_matches_oracle_at_size():
+    """BASELINE configs[4]: one L = 512 structure, virtual centre on, k = 48, 64 samples.  The oracle's teacher-forced
+    forward is run on three of the 64 samples (first, middle, last); every sample must be a valid sequence."""
+    from mpnn_amd.synthetic import synthetic_batch
+
+    kw = dict(k_neighbors=48, use_virtual_center=True)
+    model = build(kw)
+    b = synthetic_batch(B=1, L=512, seed=21, design_fraction=1.0)
+    g = {k: v.to("cuda") for k, v in b.items()}
+    out = model.sample(g["X"], g["mask"], g["chain_M"], g["residue_idx"], g["chain_encoding_all"], n_samples=64,
+                       temperature=0.1, seed=4)
+    S, lp, order = out["S"], out["log_probs"], out["order"]
+    assert S.shape == (64, 1, 512) and int(S.min()) >= 0 and int(S.max()) < 21
+    assert bool(torch.isfinite(lp).all())
+    assert bool((torch.sort(order, dim=-1).values == torch.arange(512, device="cuda")).all())
+    assert len({tuple(o.tolist()) for o in order[:, 0, :8].cpu()}) > 1, "samples draw their own decoding orders"
+    for s in (0, 31, 63):
+        ref = _oracle_log_probs(model, kw, b, S[s], order[s])
+        _assert_lp_close(lp[s], ref, f"configs[4] sample {s}")
+
+
 def test_low_temperature_is_argmax_and_seed_reproducible():
     from mpnn_amd.synthetic import synthetic_batch
 

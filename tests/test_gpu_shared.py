@@ -102,3 +102,32 @@ def test_training_mode_materialises_and_bad_shapes_raise():
     with pytest.raises(ValueError):  # 5 sequence rows on 3 structures
         model.eval()(b3["X"], torch.zeros(5, 48, dtype=torch.long, device="cuda"), b3["mask"], cm5[:1],
                      b3["residue_idx"], b3["chain_encoding_all"])
+
+
+def test_per_row_backbone_noise_is_not_shared():
+    """fix_backbone_noise with one row per SEQUENCE row on an expanded (stride-0) structure: every row is then its own
+    noisy structure (reference model_utils.py:311-312 adds the noise per row), so the shared path must not be taken;
+    noise given once per structure keeps it."""
+    model = build_model(dict(k_neighbors=32))
+    b, S, chain_M, order = make_case(1, 3, 56, seed=21)
+    B = 3
+    g = torch.Generator().manual_seed(5)
+    noise = (0.2 * torch.randn(B, 56, 4, 3, generator=g)).cuda()
+    X, mask, ridx, chain = (t.expand(B, *t.shape[1:]) for t in
+                            (b["X"], b["mask"], b["residue_idx"], b["chain_encoding_all"]))
+    with torch.no_grad():
+        got = model(X, S, mask, chain_M, ridx, chain, fix_order=order, fix_backbone_noise=noise)
+        want = model((X + noise).contiguous(), S, mask.contiguous(), chain_M, ridx.contiguous(), chain.contiguous(),
+                     fix_order=order)
+        assert torch.allclose(got, want, atol=1e-5), float((got - want).abs().max())
+        assert float((got[0] - got[1]).abs().max()) > 1e-3 or not torch.equal(S[0], S[1])
+        # n-row structure side with B-row noise
+        got2 = model(b["X"], S, b["mask"], chain_M, b["residue_idx"], b["chain_encoding_all"], fix_order=order,
+                     fix_backbone_noise=noise)
+        assert torch.equal(got2, got)
+        # one noise row per structure: shared path, equal to the materialised call
+        one = model(b["X"], S, b["mask"], chain_M, b["residue_idx"], b["chain_encoding_all"], fix_order=order,
+                    fix_backbone_noise=noise[:1])
+        full = model(X.contiguous(), S, mask.contiguous(), chain_M, ridx.contiguous(), chain.contiguous(),
+                     fix_order=order, fix_backbone_noise=noise[:1].repeat(B, 1, 1, 1))
+        assert torch.equal(one, full)

@@ -228,7 +228,7 @@ def test_edge_update_with_dropout_vs_aten(p_drop):
 
     training._ZEROS.reset(torch.device(d, torch.cuda.current_device()))
     hE = training.FromNaturalFn.apply(g, hE_nat)
-    out = training.EdgeUpdateFn.apply(g, training.GradSlot(), p_drop, seed, hE, P, Q, W11b, W12, b12, W13, b13, lnw, lnb)
+    out = training.EdgeUpdateFn.apply(g, training.GradSlot(), training.GradSlot(), p_drop, seed, hE, P, Q, W11b, W12, b12, W13, b13, lnw, lnb)
     out_nat = engine.edges_to_natural(out.detach(), N, K)
     out.backward(engine.edges_from_natural(upstream, N, K))
     got = [p.grad.clone() for p in params]
@@ -414,3 +414,24 @@ def test_energy_style_loss_gradients_vs_oracle():
     want = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items() if v.requires_grad}
     assert abs(loss.item() - loss_ref.item()) <= 1e-4 * max(1.0, abs(loss_ref.item()))
     compare_grads({n: got.get(n, torch.zeros_like(v)) for n, v in want.items()}, want)
+
+
+@pytest.mark.parametrize("n_enc", [3, 0])
+def test_second_backward_over_the_same_graph(n_enc):
+    """retain_graph=True and a second backward: the shared per-edge gradient buffers must start afresh (with no encoder
+    every decoder message kernel accumulates into ONE buffer that the featurizer's backward consumes)."""
+    from mpnn_amd import training
+    from mpnn_amd.synthetic import synthetic_batch
+
+    kw = dict(k_neighbors=24, num_encoder_layers=n_enc)
+    b = {k: v.cuda() for k, v in synthetic_batch(B=2, L=40, seed=31, lengths=[40, 29], n_chains=2).items()}
+    model = build(kw)
+    lp = training.forward_train(model, b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"],
+                                b["chain_encoding_all"], fix_order=b["fix_order"])
+    _, loss = training.loss_smoothed(b["S"], lp, b["mask"] * b["chain_M"])
+    loss.backward(retain_graph=True)
+    first = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    for n, p in model.named_parameters():
+        assert torch.allclose(p.grad, first[n], rtol=1e-5, atol=1e-9), n
