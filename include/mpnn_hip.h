@@ -258,6 +258,17 @@ int mpnn_pack_blocks(const float* const* blocks, const int* ld, const int* trans
 int mpnn_node_wgrad(const float* dY, int ldy, int out_f, const float* X, int ldx, int in_f, int n_rows, float* dW,
                     int ldw, float* dbias, float* workspace, int workspace_floats, void* stream);
 
+/* mpnn_node_wgrad without a workspace argument and WITHOUT ANY ALLOCATION.  No counterpart in the reference: it exists
+ * for callers that cannot allocate device memory - code under HIP-graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  Same arithmetic and kernels as mpnn_node_wgrad; the split-K partials go to a device array built
+ * into the library (128 partials x 16512 floats = 8.06 MiB per GPU, held until the process ends).
+ * Limits: ceil(out_f/128) * ceil(in_f/128) <= 128 output blocks and n_rows <= 2^24, else -1 with a message (use
+ * mpnn_node_wgrad).  The first call on a device looks up that device's copy of the array (make it outside a capture).
+ * All calls on one GPU share the array: calls that overlap on one GPU (two streams, two threads) race - serialise them.
+ * Accumulates like mpnn_node_wgrad: zero dW / dbias first. */
+int mpnn_node_wgrad_noalloc(const float* dY, int ldy, int out_f, const float* X, int ldx, int in_f, int n_rows,
+                            float* dW, int ldw, float* dbias, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Autoregressive sampling (BASELINE configs[4]).  The reference has no sampler; the contract is
  * that a teacher-forced forward (:427-529) on the sampled sequence with the same decoding order returns, at every

@@ -8,6 +8,7 @@
 // fp32 products) straight from global memory, and stores its partial tile to a workspace that a second small
 // kernel adds up (per-element atomics from every workgroup cost more than the contraction itself).
 #include "mpnn_bwd_common.h"
+#include <mutex>
 
 constexpr int NW_PART = 128 * 128 + 128;  // floats of one workgroup partial (tile | bias sums)
 
@@ -534,6 +535,64 @@ extern "C" int mpnn_node_wgrad(const float* dY, int ldy, int out_f, const float*
   jb.blk0[0] = 0;
   jb.blk0[1] = jb.ny[0] * ((in_f + 127) / 128);
   return launch_node_wgrads(jb, n_rows, workspace, workspace_floats, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// mpnn_node_wgrad for callers that cannot allocate (HIP-graph capture, serving loops, harnesses that forbid hipMalloc):
+// the split-K partials go to a file-scope device array instead of a caller workspace.  Each GPU holds its own copy of
+// the array (NOALLOC_PARTS x 16512 floats = 8.06 MiB) at its own address until the process ends; the address is looked
+// up once per device (hipGetSymbolAddress) and only that pointer is ever handed to kernels or runtime calls.
+// Nothing in the array has to start at zero: k_node_wgrad overwrites every partial that k_node_wgrad_reduce reads.
+// Calls that overlap on one GPU (two streams, two host threads) share the array and race.
+// ---------------------------------------------------------------------------
+constexpr int NOALLOC_PARTS = 128;   // partial tiles: 128x128 output blocks x row chunks
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static __device__ __align__(256) float scratch[(size_t)NOALLOC_PARTS * NW_PART];
+static float* g_scratch_ptr[NOALLOC_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+static int scratch_of_current_device(float** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) {
+    mpnn_set_error(hipGetErrorString(e));
+    return (int)e;
+  }
+  MPNN_CHECK_ARG(dev >= 0 && dev < NOALLOC_MAX_DEVICES, "mpnn_node_wgrad_noalloc: device ordinal out of range");
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    float* p = nullptr;
+    e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));  // this device's copy of the array
+    if (e != hipSuccess || !p) {
+      mpnn_set_error(e != hipSuccess ? hipGetErrorString(e) : "mpnn_node_wgrad_noalloc: no address for the scratch array");
+      return e != hipSuccess ? (int)e : -1;
+    }
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return 0;
+}
+
+extern "C" int mpnn_node_wgrad_noalloc(const float* dY, int ldy, int out_f, const float* X, int ldx, int in_f, int n_rows,
+                                       float* dW, int ldw, float* dbias, void* stream) {
+  MPNN_CHECK_ARG(dY && X && dW, "mpnn_node_wgrad_noalloc: null pointer");
+  MPNN_CHECK_ARG(n_rows > 0 && out_f > 0 && in_f > 0 && ldy >= out_f && ldx >= in_f && ldw >= in_f,
+                 "mpnn_node_wgrad_noalloc: bad sizes");
+  const long long blocks = (long long)((out_f + 127) / 128) * ((in_f + 127) / 128);
+  MPNN_CHECK_ARG(blocks <= NOALLOC_PARTS && n_rows <= (1 << 24),
+                 "mpnn_node_wgrad_noalloc: beyond the built-in scratch (ceil(out_f/128) x ceil(in_f/128) <= 128 output "
+                 "blocks, n_rows <= 2^24); use mpnn_node_wgrad with a caller workspace");
+  float* ws = nullptr;
+  const int rc = scratch_of_current_device(&ws);
+  if (rc) return rc;
+  WgradJobs jb = {};
+  jb.n = 1;
+  jb.dY[0] = dY; jb.X[0] = X; jb.dW[0] = dW; jb.db[0] = dbias;
+  jb.ldy[0] = ldy; jb.out_f[0] = out_f; jb.ldx[0] = ldx; jb.in_f[0] = in_f; jb.ldw[0] = ldw;
+  jb.ny[0] = (out_f + 127) / 128;
+  jb.blk0[0] = 0;
+  jb.blk0[1] = (int)blocks;
+  return launch_node_wgrads(jb, n_rows, ws, NOALLOC_PARTS * NW_PART, (hipStream_t)stream);
 }
 
 extern "C" int mpnn_node_wgrad_batch(int n_jobs, const float* const* dY, const int* ldy, const int* out_f,
