@@ -51,6 +51,12 @@ int mpnn_pack_linear(const float* W, int out_f, int in_f, int ld, int col0, floa
 int mpnn_pack_linear_split(const float* W, int out_f, int in_f, int ld, int col0, int rot, void* packed,
                            void* stream);
 
+/* Element-wise probe of the device arithmetic every MLP on the path is built from (used by the unit tests):
+ * mode 0: y = GELU(x), the exact-erf form of nn.GELU() (:70, :115, :149) as the kernels evaluate it
+ *         (relu(x) - |x| 2^(-Q(|x|)), Q a degree-6 polynomial; within 3e-7 absolute of the fp64 erf form);
+ * mode 1: y = hi + lo of the f16 hi/lo operand split that feeds the MFMAs (|x - y| <= 2^-21 |x| for 6e-5 < |x| < 65504). */
+int mpnn_probe_elementwise(const float* x, int n, int mode, float* y, void* stream);
+
 /* PositionalEncodings as a table: table[d][p] = W[p][d] + bias[p]  (one_hot(d) @ W^T + b, :168-177). */
 int mpnn_pos_table(const float* W, const float* bias, int nbuckets /*66*/, int npos /*16*/, float* table,
                    void* stream);

@@ -53,10 +53,15 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// exact-erf GELU (nn.GELU() default; reference model_utils.py:70,115,149):  0.5 x (1 + erf(x / sqrt 2)).
-// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7 + fp32 rounding), branch free:
-//   erf(|z|) = 1 - (a1 t + ... + a5 t^5) exp(-z^2),  t = 1 / (1 + p |z|)
-// ~15 VALU instructions, two of them transcendental (v_rcp_f32, v_exp_f32).
+// exact-erf GELU (nn.GELU() default; reference model_utils.py:70,115,149):  x Phi(x) = relu(x) - |x| Phi(-|x|).
+// Phi(-a) = 2^(-Q(a)): Q = -log2 Phi(-a) is smooth and nearly quadratic, so a degree-6 polynomial in a = |x| (weighted
+// minimax fit, tools/fit_gelu.py) reproduces |x| Phi(-|x|) to 5.1e-8 absolute for every x; in fp32 the whole function is
+// within 2.9e-7 of the fp64 erf form (half an ulp of the result at |x| ~ 4 - the output rounding, not the fit).
+// 10 VALU instructions, ONE transcendental, no division:  min, 6 fma, exp2, max, fma  (|x| and the negations are
+// free source modifiers).  The clamp at 12 only keeps the polynomial (negative leading coefficient) out of the region
+// where it would turn over; Phi(-12) ~ 1.8e-33 is already 0 in the result.
+// MPNN_GELU_AS selects the round-1 form (Abramowitz-Stegun 7.1.26 erfc: rcp + exp2 + 12 plain ops, 3.3e-7).
+#ifdef MPNN_GELU_AS
 __device__ __forceinline__ float gelu(float x) {
   const float z = x * 0.70710678118654752440f;
   const float az = fabsf(z);
@@ -71,6 +76,20 @@ __device__ __forceinline__ float gelu(float x) {
   const float r = (0.5f * fabsf(x)) * (p * e);         // 0.5 |x| erfc(|z|)  >= 0
   return fmaxf(x, 0.f) - r;                           // x Phi(x) = relu(x) - 0.5 |x| erfc(|x| / sqrt 2)
 }
+#else
+__device__ __forceinline__ float gelu(float x) {
+  const float ax = fabsf(x);
+  const float a = fminf(ax, 12.0f);
+  float q = fmaf(-3.309285239e-05f, a, 7.692201762e-04f);
+  q = fmaf(q, a, -8.080718108e-03f);
+  q = fmaf(q, a, 5.341210589e-02f);
+  q = fmaf(q, a, 4.587709606e-01f);
+  q = fmaf(q, a, 1.151201725e+00f);
+  q = fmaf(q, a, 9.999930859e-01f);
+  const float e = __builtin_amdgcn_exp2f(-q);          // Phi(-|x|)
+  return fmaf(-ax, e, fmaxf(x, 0.f));
+}
+#endif
 
 __device__ __forceinline__ f32x4 gelu4(f32x4 v) {
 #ifdef MPNN_ABL_NOGELU  // timing-only ablation build: never shipped
@@ -168,31 +187,52 @@ struct BFrag {
 };
 
 // hi by v_cvt_pkrtz_f16_f32 (two conversions and the packing in one instruction; truncation instead of rounding is
-// immaterial because lo = f16(x - hi) picks up the exact residual: |x - hi - lo| <= 2^-21 |x|)
+// immaterial because lo = f16(x - hi) picks up the exact residual: |x - hi - lo| <= 2^-21 |x|).
+// lo by the mixed-precision FMA: v_fma_mixlo/mixhi_f16 read hi's half straight out of the packed register, subtract it
+// from the fp32 value and round the difference to f16 into the low / high half of the destination: ONE instruction
+// per element instead of cvt_f32_f16 + sub + (half a) cvt_pkrtz  =>  1.5 instead of 3 VALU instructions per element.
+// hipcc pads no hazards for instructions inside an asm statement, and a VGPR written by a VALU instruction needs two
+// wait states before an MFMA may read it as an operand: the statement ends with s_nop 1 (one per eight elements).
+// Outputs are early-clobber: they are written before the last input is read.
 typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split_pair(const f32x4 a, const f32x4 b, BFrag& o) {
+#if defined(MPNN_FAST) || defined(MPNN_SPLIT_CVT)
   const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  u32x4 hi, lo;
 #pragma unroll
-  for (int j = 0; j < 8; j += 2) {
-#ifdef MPNN_SPLIT_RTN
-    const _Float16 h0 = (_Float16)v[j], h1 = (_Float16)v[j + 1];
-#else
-    const fp16x2_t hp = __builtin_amdgcn_cvt_pkrtz(v[j], v[j + 1]);
-    const _Float16 h0 = (_Float16)hp[0], h1 = (_Float16)hp[1];
-#endif
-    o.hi[j] = h0;
-    o.hi[j + 1] = h1;
-#ifndef MPNN_FAST
-#ifdef MPNN_SPLIT_RTN
-    o.lo[j] = (_Float16)(v[j] - (float)h0);
-    o.lo[j + 1] = (_Float16)(v[j + 1] - (float)h1);
-#else
-    const fp16x2_t lp = __builtin_amdgcn_cvt_pkrtz(v[j] - (float)h0, v[j + 1] - (float)h1);
-    o.lo[j] = (_Float16)lp[0];
-    o.lo[j + 1] = (_Float16)lp[1];
-#endif
+  for (int j = 0; j < 4; ++j) {
+    const fp16x2_t hp = __builtin_amdgcn_cvt_pkrtz(v[2 * j], v[2 * j + 1]);
+    hi[j] = __builtin_bit_cast(unsigned, hp);
+#ifndef MPNN_FAST  // round-1 form: convert hi back, subtract, convert again (3 instructions per element)
+    const fp16x2_t lp = __builtin_amdgcn_cvt_pkrtz(v[2 * j] - (float)hp[0], v[2 * j + 1] - (float)hp[1]);
+    lo[j] = __builtin_bit_cast(unsigned, lp);
 #endif
   }
+  o.hi = __builtin_bit_cast(h8, hi);
+#ifndef MPNN_FAST
+  o.lo = __builtin_bit_cast(h8, lo);
+#endif
+#else
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  asm("v_cvt_pkrtz_f16_f32 %0, %8, %9\n\t"
+      "v_cvt_pkrtz_f16_f32 %1, %10, %11\n\t"
+      "v_cvt_pkrtz_f16_f32 %2, %12, %13\n\t"
+      "v_cvt_pkrtz_f16_f32 %3, %14, %15\n\t"
+      "v_fma_mixlo_f16 %4, -%0, 1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %5, -%1, 1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %6, -%2, 1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %7, -%3, 1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %4, -%0, 1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %5, -%1, 1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %6, -%2, 1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %7, -%3, 1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 1"
+      : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+      : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+  o.hi = __builtin_bit_cast(h8, (u32x4){h0, h1, h2, h3});
+  o.lo = __builtin_bit_cast(h8, (u32x4){l0, l1, l2, l3});
+#endif
 }
 
 __device__ __forceinline__ f32x4 mfma_split(const h8 a_hi, const h8 a_lo, const BFrag& b, f32x4 acc) {

@@ -21,6 +21,32 @@
 //   * the edge update streams its third weight matrix from L2 three fragments ahead.
 // Two waves per SIMD (8-wave workgroups) let one wave's GELU / reductions run under the other's MFMAs.
 #include "mpnn_edge_common.h"
+#include <stdio.h>
+
+// MPNN_STAMP: diagnostic build only (never shipped): per-phase shader-clock totals of the persistent edge kernels,
+// summed over all waves into g_stamp and printed by the launcher at the NEXT launch of the kernel.
+#ifdef MPNN_STAMP
+__device__ unsigned long long g_stamp[16];
+#define STAMP_DECL long long st_t = __builtin_amdgcn_s_memtime(); unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(i) do { const long long st_n = __builtin_amdgcn_s_memtime(); st_acc[i] += (unsigned long long)(st_n - st_t); st_t = st_n; } while (0)
+#define STAMP_FLUSH(base) do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_stamp[(base) + i_], st_acc[i_]); } } while (0)
+static void stamp_report(const char* what, int base) {
+  unsigned long long h[16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof(h)) != hipSuccess) return;
+  unsigned long long tot = 0;
+  for (int i = 0; i < 8; ++i) tot += h[base + i];
+  if (!tot) return;
+  fprintf(stderr, "[stamp %s]", what);
+  for (int i = 0; i < 8; ++i) fprintf(stderr, " p%d=%.1f%%", i, 100.0 * h[base + i] / tot);
+  fprintf(stderr, "  total %.3e wave-cycles\n", (double)tot);
+  unsigned long long z[8] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z), base * sizeof(unsigned long long));
+}
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH(base)
+#endif
 
 MPNN_KERNELS_BEGIN
 
@@ -157,9 +183,11 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 #pragma unroll
     for (int c = 0; c < KT; ++c) h1[t][c] = row_tile(row[c], t);
 
+  STAMP_DECL;
   for (; node < Nend; node += stride) {
     const int nxt = (node + stride < Nend) ? node + stride : Nend - 1;  // tail: harmless re-load of a valid residue
     LAUNDER(b2);
+    STAMP(7);
     f32x4 p[MPNN_NT];  // P_i: needed only after layer 1
     {
       const float* Pi = Pbuf + (size_t)node * ldp + offP + 4 * g;
@@ -168,6 +196,7 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
     }
     const int node_e = (DEC && node >= enc_mod) ? node % enc_mod : node;
     layer1_stream<KT>(W1s, hE + (size_t)node_e * (MPNN_NT * KT * 64) + lane, lane, h1);
+    STAMP(0);
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
@@ -181,6 +210,7 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
     }
     BFrag hb[NKK][KT];
     tile_to_bfrag<MPNN_NT, KT, true>(h1, hb);
+    STAMP(1);
     // next residue's scalars (their loads fly under layer 2)
     const float* rown[KT];
     float sn[KT], wn[KT];
@@ -193,6 +223,7 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
       for (int c = 0; c < KT; ++c) y[t][c] = bb;
     }
     split_gemm<KT, NKK, 0, MPNN_NT>(W2s, lane, hb, y);
+    STAMP(2);
     if (SAVE) {
       f32x4* o = sv2 + (size_t)node * (MPNN_NT * KT * 64) + lane;
 #pragma unroll
@@ -218,7 +249,9 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
       s[c] = sn[c];
       w[c] = wn[c];
     }
+    STAMP(3);
   }
+  STAMP_FLUSH(0);
 }
 
 // ---------------------------------------------------------------------------
@@ -265,8 +298,10 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #pragma unroll
     for (int c = 0; c < KT; ++c) h2[t][c] = row_tile(row[c], t);
 
+  STAMP_DECL;
   for (; node < Nend; node += stride) {
     const int nxt = (node + stride < Nend) ? node + stride : Nend - 1;
+    STAMP(7);
     LAUNDER(b12);
     LAUNDER(b13);
     LAUNDER(ln_w);
@@ -287,6 +322,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #pragma unroll
       for (int c = 0; c < KT; ++c) h1[t][c] = h2[t][c];
     layer1_stream<KT>(W1s, x, lane, h1);
+    STAMP(0);
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
@@ -300,6 +336,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
     }
     BFrag hb[NKK][KT];
     tile_to_bfrag<MPNN_NT, KT, true>(h1, hb);
+    STAMP(1);
     const float* rown[KT];
     setup(nxt, rown);
     // ---- layer 2
@@ -310,6 +347,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
       for (int c = 0; c < KT; ++c) h2[t][c] = bb;
     }
     split_gemm<KT, NKK, 0, MPNN_NT>(W2s, lane, hb, h2);
+    STAMP(2);
     if (SAVE) {
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t)
@@ -327,6 +365,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
       for (int c = 0; c < KT; ++c) h1[t][c] = SAVE ? f32x4{0.f, 0.f, 0.f, 0.f} : x[(t * KT + c) * 64];
 #endif
     tile_to_bfrag<MPNN_NT, KT, true>(h2, hb);
+    STAMP(3);
     // ---- layer 3; W13 fragments (hi, lo) from L2, D steps ahead.  step q = kk * 8 + to
 #ifdef MPNN_ABL_W3LDS  // timing-only ablation build: never shipped
     split_gemm<KT, NKK, 0, MPNN_NT>(W2s, lane, hb, h1);
@@ -355,6 +394,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
       }
     }
 #endif
+    STAMP(4);
     // next residue's Q' rows -> h2 (carried to the next iteration), under LayerNorm + store
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
@@ -385,7 +425,9 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
       for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(h1[t][c], &xo[(t * KT + c) * 64]);
+    STAMP(5);
   }
+  STAMP_FLUSH(8);
 }
 
 // ---------------------------------------------------------------------------
@@ -749,6 +791,9 @@ extern "C" int MPNN_API(mpnn_enc_message)(const float* hE_frag, const float* PQ,
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && ldpq >= 128 && mult4(ldpq, offP, offQ),
                  "mpnn_enc_message: bad sizes (strides/offsets must be multiples of 4 floats)");
   const int N = B * L, KT = (K + 15) / 16;
+#ifdef MPNN_STAMP
+  stamp_report("message: layer1 | gelu1+split | layer2 | gelu2+reduce+next rows | .. | loop top", 0);
+#endif
   if (MPNN_MSG_TILEWISE || KT > 3) {
     dim3 grid(edge_grid(N, MPNN_MSGT_WAVES)), block(MPNN_MSGT_WAVES * 64);
     hipLaunchKernelGGL((k_message_tiles<false>), grid, block, 0, (hipStream_t)stream, (const f32x4*)hE_frag, PQ, ldpq,
@@ -773,6 +818,9 @@ extern "C" int MPNN_API(mpnn_enc_edge_update)(float* hE_frag, const float* PQ, i
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && ldpq >= 128 && mult4(ldpq, offP, offQ),
                  "mpnn_enc_edge_update: bad sizes (strides/offsets must be multiples of 4 floats)");
   const int N = B * L, KT = (K + 15) / 16;
+#ifdef MPNN_STAMP
+  stamp_report("edge update: layer1 | gelu1+split | layer2 | res load+gelu2+split | layer3 | LN+store | .. | loop top", 8);
+#endif
   dim3 grid(edge_grid(N, MPNN_UPD_WAVES)), block(MPNN_UPD_WAVES * 64);
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_enc_edge_update<kKT, false>), grid, block, 0, (hipStream_t)stream,
                                      (f32x4*)hE_frag, PQ, ldpq, offP, PQ, ldpq, offQ, E_idx32, (const h8*)W11b_packed,

@@ -124,7 +124,37 @@ k_loss_smoothed(const float* __restrict__ logp, const long long* __restrict__ S,
   if (threadIdx.x == 0) unsafeAtomicAdd(loss_sum, (part[0] + part[1]) + (part[2] + part[3]));
 }
 
+// element-wise probes of the two device helpers every MLP on the path is built from (unit tests of the arithmetic):
+//   mode 0: y = gelu(x)          (mpnn_common.h; reference nn.GELU(), :70, :115, :149)
+//   mode 1: y = hi + lo of the f16 hi/lo split the matrix-pipe kernels feed their MFMAs with (x must be |x| < 65504)
+__global__ void k_probe(const float* __restrict__ x, int n, int mode, float* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i8 = i * 8;
+  if (i8 >= n) return;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = i8 + j < n ? x[i8 + j] : 0.f;
+  if (mode == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = gelu(v[j]);
+  } else {
+    BFrag b;
+    split_pair(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)b.hi[j] + (float)b.lo[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (i8 + j < n) y[i8 + j] = v[j];
+}
+
 }  // namespace
+
+extern "C" int mpnn_probe_elementwise(const float* x, int n, int mode, float* y, void* stream) {
+  MPNN_CHECK_ARG(x && y && n > 0 && (mode == 0 || mode == 1), "mpnn_probe_elementwise: bad arguments");
+  hipLaunchKernelGGL(k_probe, dim3((n + 2047) / 2048), dim3(256), 0, (hipStream_t)stream, x, n, mode, y);
+  MPNN_LAUNCH_CHECK();
+}
 
 extern "C" int mpnn_logits_log_softmax_bwd(const float* d_log_probs, const float* log_probs, const float* hV,
                                            const float* W_out, int n_letters, int n_nodes, float* d_hV, float* dW,
