@@ -78,8 +78,9 @@ __device__ __forceinline__ float gelu(float x) {
 }
 #else
 __device__ __forceinline__ float gelu(float x) {
+  // min / max through v_med3_f32: fminf / fmaxf make hipcc canonicalise their inputs first (one more v_max each)
   const float ax = fabsf(x);
-  const float a = fminf(ax, 12.0f);
+  const float a = __builtin_amdgcn_fmed3f(ax, 0.0f, 12.0f);
   float q = fmaf(-3.309285239e-05f, a, 7.692201762e-04f);
   q = fmaf(q, a, -8.080718108e-03f);
   q = fmaf(q, a, 5.341210589e-02f);
@@ -87,7 +88,7 @@ __device__ __forceinline__ float gelu(float x) {
   q = fmaf(q, a, 1.151201725e+00f);
   q = fmaf(q, a, 9.999930859e-01f);
   const float e = __builtin_amdgcn_exp2f(-q);          // Phi(-|x|)
-  return fmaf(-ax, e, fmaxf(x, 0.f));
+  return fmaf(-ax, e, __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()));
 }
 #endif
 
@@ -191,9 +192,8 @@ struct BFrag {
 // lo by the mixed-precision FMA: v_fma_mixlo/mixhi_f16 read hi's half straight out of the packed register, subtract it
 // from the fp32 value and round the difference to f16 into the low / high half of the destination: ONE instruction
 // per element instead of cvt_f32_f16 + sub + (half a) cvt_pkrtz  =>  1.5 instead of 3 VALU instructions per element.
-// hipcc pads no hazards for instructions inside an asm statement, and a VGPR written by a VALU instruction needs two
-// wait states before an MFMA may read it as an operand: the statement ends with s_nop 1 (one per eight elements).
-// Outputs are early-clobber: they are written before the last input is read.
+// Inputs must come from VALU instructions or loads, never straight from an MFMA (hipcc inserts the MFMA -> VALU wait
+// states only for instructions it can see).
 typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split_pair(const f32x4 a, const f32x4 b, BFrag& o) {
@@ -214,24 +214,21 @@ __device__ __forceinline__ void split_pair(const f32x4 a, const f32x4 b, BFrag& 
   o.lo = __builtin_bit_cast(h8, lo);
 #endif
 #else
-  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-  asm("v_cvt_pkrtz_f16_f32 %0, %8, %9\n\t"
-      "v_cvt_pkrtz_f16_f32 %1, %10, %11\n\t"
-      "v_cvt_pkrtz_f16_f32 %2, %12, %13\n\t"
-      "v_cvt_pkrtz_f16_f32 %3, %14, %15\n\t"
-      "v_fma_mixlo_f16 %4, -%0, 1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixlo_f16 %5, -%1, 1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixlo_f16 %6, -%2, 1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixlo_f16 %7, -%3, 1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %4, -%0, 1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %5, -%1, 1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %6, -%2, 1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %7, -%3, 1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "s_nop 1"
-      : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
-      : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
-  o.hi = __builtin_bit_cast(h8, (u32x4){h0, h1, h2, h3});
-  o.lo = __builtin_bit_cast(h8, (u32x4){l0, l1, l2, l3});
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  u32x4 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    hi[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2 * j], v[2 * j + 1]));
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=&v"(l) : "v"(hi[j]), "v"(v[2 * j]));
+    asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi[j]), "v"(v[2 * j + 1]));
+    lo[j] = l;
+  }
+  // hipcc pads no hazard behind an asm statement: two wait states between the last v_fma_mix write and an MFMA that
+  // reads the fragment; tying the nop to the whole register tuple also orders it between the two
+  asm("s_nop 1" : "+v"(lo));
+  o.hi = __builtin_bit_cast(h8, hi);
+  o.lo = __builtin_bit_cast(h8, lo);
 #endif
 }
 
@@ -319,6 +316,17 @@ __device__ __forceinline__ void split_kstep_stream(WRing<D>& r, const h8* __rest
 #endif
 #pragma unroll
     for (int c = 0; c < KT; ++c) Y[to][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, B[c].hi, Y[to][c], 0, 0, 0);
+#ifdef MPNN_SCHED_PIN
+    // pin the order hipcc would otherwise undo (it sinks the ring's reads next to their first use): this step's
+    // fragment reads first, then its MFMAs, whose operands were read D steps earlier
+#ifndef MPNN_FAST
+    if (q + D < NKK * NTO) __builtin_amdgcn_sched_group_barrier(0x120, 2, 0);  // 2 memory reads (VMEM 0x020 | DS 0x100)
+    __builtin_amdgcn_sched_group_barrier(0x008, 3 * KT, 0);
+#else
+    if (q + D < NKK * NTO) __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, KT, 0);
+#endif
+#endif
   }
 }
 
@@ -347,6 +355,25 @@ __device__ __forceinline__ void tile_to_bfrag(const f32x4 (&V)[NT_][KT], BFrag (
         split_pair(V[2 * kk][c], V[2 * kk + 1][c], B[kk][c]);
     }
     __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// LayerNorm statistics of each column (mean, 1 / sqrt(var + eps)) over its 128 features
+template <int KT>
+__device__ __forceinline__ void tile_layernorm_stats(const f32x4 (&V)[MPNN_NT][KT], float (&mean)[KT], float (&rstd)[KT]) {
+#pragma unroll
+  for (int c = 0; c < KT; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) s += (V[t][c].x + V[t][c].y) + (V[t][c].z + V[t][c].w);
+    mean[c] = quarter_sum(s) * (1.0f / MPNN_H);
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      const f32x4 d = V[t][c] - mean[c];
+      q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+    rstd[c] = rsqrtf(quarter_sum(q) * (1.0f / MPNN_H) + MPNN_LN_EPS);
   }
 }
 

@@ -61,48 +61,102 @@ MPNN_KERNELS_BEGIN
 #ifndef MPNN_UPD_WAVES
 #define MPNN_UPD_WAVES 8
 #endif
+// tuning switches of the edge update's epilogue (A/B builds): where the next residue's first hE k-step (X0) and its
+// gathered rows (ROWS) are issued.  X0: 0 = at the loop top, 1 = after the LayerNorm statistics (before the stores).
+// ROWS: 0 = right after layer 3, 1 = after the LayerNorm statistics.
+// LDS weight fragments are read MPNN_LDS_RING (to, kk) steps ahead of the MFMAs that use them (0: read and wait
+// in place, which is what hipcc schedules on its own at this register pressure: ~64 exposed LDS latencies per layer)
+#ifndef MPNN_LDS_RING
+#define MPNN_LDS_RING 0
+#endif
+// Waves w and w + 4 of an 8-wave workgroup share a SIMD and run the same program: started together they stay in
+// lockstep - both in their MFMA phase (sharing the matrix pipe), then both in their GELU phase (the matrix pipe idle);
+// measured: kernel time = MFMA time + VALU time.  Delaying waves 4-7 once, by about half a phase, puts one wave's MFMAs
+// beside the other's VALU work for the rest of the kernel.  Unit: s_sleep ticks of 64 cycles; 0 = off.
+#ifndef MPNN_STAGGER
+#define MPNN_STAGGER 0
+#endif
+#ifndef MPNN_UPD_X0
+#define MPNN_UPD_X0 0
+#endif
+#ifndef MPNN_UPD_ROWS
+#define MPNN_UPD_ROWS 1
+#endif
 #ifndef MPNN_UPD_RING
-#define MPNN_UPD_RING 3  // W13 fragments in flight ahead of their MFMAs (edge update, layer 3)
+#define MPNN_UPD_RING 7  // W13 lo fragments in flight ahead of their MFMAs (edge update, layer 3)
 #endif
 
 // layer 1 of every edge MLP: acc += W1b * hE[node]; hE feature tiles stream from HBM one k-step
 // (two tiles) ahead of their MFMAs and are split to f16 hi/lo on the fly
 template <int KT>
+__device__ __forceinline__ void load_kstep(const f32x4* __restrict__ x, int kk, f32x4 (&xt)[2][KT]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int c = 0; c < KT; ++c)
+#ifdef MPNN_ABL_NOXLOAD
+      xt[u][c] = f32x4{1.f, 2.f, 3.f, 4.f};
+#else
+      xt[u][c] = x[((2 * kk + u) * KT + c) * 64];
+#endif
+}
+
+// x0: the tiles of k-step 0, loaded by the caller (persistent kernels issue them one phase early, before the previous
+// residue's epilogue: a wave's vector-memory operations complete in issue order, so a load issued behind the epilogue's
+// stores and gathers would wait for all of them)
+template <int KT>
 __device__ __forceinline__ void layer1_stream(const h8* Ws, const f32x4* __restrict__ x, int lane,
-                                              f32x4 (&acc)[MPNN_NT][KT]) {
+                                              f32x4 (&acc)[MPNN_NT][KT], const f32x4 (&x0)[2][KT]) {
   f32x4 xb[2][2][KT];
 #pragma unroll
   for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int c = 0; c < KT; ++c) xb[0][u][c] = x[(u * KT + c) * 64];
+    for (int c = 0; c < KT; ++c) xb[0][u][c] = x0[u][c];
+#if MPNN_LDS_RING
+  WRing<MPNN_LDS_RING> ring;
+  wring_prologue<NKK, MPNN_NT, MPNN_LDS_RING>(ring, Ws + lane);
+#endif
 #pragma unroll
   for (int kk = 0; kk < NKK; ++kk) {
-    if (kk + 1 < NKK) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int c = 0; c < KT; ++c)
-#ifdef MPNN_ABL_NOXLOAD
-          xb[(kk + 1) & 1][u][c] = f32x4{1.f, 2.f, 3.f, 4.f};
-#else
-          xb[(kk + 1) & 1][u][c] = x[((2 * (kk + 1) + u) * KT + c) * 64];
-#endif
-    }
+    if (kk + 1 < NKK) load_kstep<KT>(x, kk + 1, xb[(kk + 1) & 1]);
     BFrag b[KT];
 #pragma unroll
     for (int c = 0; c < KT; ++c) split_pair(xb[kk & 1][0][c], xb[kk & 1][1][c], b[c]);
+#if MPNN_LDS_RING
+    split_kstep_stream<KT, NKK, MPNN_NT, MPNN_LDS_RING>(ring, Ws + lane, kk, b, acc);
+#else
     split_kstep<KT, NKK, 0, MPNN_NT>(Ws, kk, lane, b, acc);
+#endif
     FENCE();
   }
 }
 
-// masked neighbour sum of gelu(y) over the residue's edges -> gsum
+// Y += W X with W's fragments in LDS, read MPNN_LDS_RING steps ahead
 template <int KT>
+__device__ __forceinline__ void lds_gemm(const h8* Ws, int lane, const BFrag (&B)[NKK][KT], f32x4 (&Y)[MPNN_NT][KT]) {
+#if MPNN_LDS_RING
+  split_gemm_stream<KT, NKK, MPNN_NT, MPNN_LDS_RING>(Ws + lane, B, Y);
+#else
+  split_gemm<KT, NKK, 0, MPNN_NT>(Ws, lane, B, Y);
+#endif
+}
+
+template <int KT>
+__device__ __forceinline__ void layer1_stream(const h8* Ws, const f32x4* __restrict__ x, int lane,
+                                              f32x4 (&acc)[MPNN_NT][KT]) {
+  f32x4 x0[2][KT];
+  load_kstep<KT>(x, 0, x0);
+  layer1_stream<KT>(Ws, x, lane, acc, x0);
+}
+
+// masked neighbour sum of gelu(y) over the residue's edges -> gsum
+template <int KT, typename Hook>
 __device__ __forceinline__ void reduce_store(f32x4 (&y)[MPNN_NT][KT], const float (&w)[KT], float* __restrict__ out,
-                                             int lane) {
+                                             int lane, Hook midway) {
   const int g = lane >> 4, col = lane & 15;
 #pragma unroll
   for (int t = 0; t < MPNN_NT; ++t) {
+    if (t == MPNN_NT / 2) midway();  // half of y is dead: room for the next residue's first loads
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < KT; ++c) s += gelu4(y[t][c]) * w[c];
@@ -130,8 +184,10 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
           const float* __restrict__ b2, int N, int L, int K, float* __restrict__ gsum, float* __restrict__ cnt,
           f32x4* __restrict__ sv1, f32x4* __restrict__ sv2, int enc_mod) {
   __shared__ h8 lds[2 * WSPLIT];
+  __shared__ __align__(16) float b2s[MPNN_H];  // bias from LDS: a global load would queue behind the row gathers
   lds_fill(lds, W1b, WSPLIT);
   lds_fill(lds + WSPLIT, W2, WSPLIT);
+  if (threadIdx.x < MPNN_H) b2s[threadIdx.x] = b2[threadIdx.x];
   __syncthreads();
   const h8* W1s = lds;
   const h8* W2s = lds + WSPLIT;
@@ -142,6 +198,7 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
   const int stride = rr.stride, Nend = rr.end;
   int node = rr.first;
   if (node >= Nend) return;
+  if (MPNN_STAGGER && __builtin_amdgcn_readfirstlane(wave) >= MPNN_MSG_WAVES / 2) __builtin_amdgcn_s_sleep(MPNN_STAGGER);
 
   // per-edge scalars of a residue: gathered row, scale s (dec), reduction weight w
   // shared-structure decoding (DEC, enc_mod < N): rows of the batch beyond the first enc_mod residues are further
@@ -182,11 +239,16 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
   for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
     for (int c = 0; c < KT; ++c) h1[t][c] = row_tile(row[c], t);
+  auto edge_block = [&](int nd) {  // a residue's hE block (shared-structure decoding reads it at residue % enc_mod)
+    const int ne = (DEC && nd >= enc_mod) ? nd % enc_mod : nd;
+    return hE + (size_t)ne * (MPNN_NT * KT * 64) + lane;
+  };
+  f32x4 x0[2][KT];  // k-step 0 of the residue's hE, always loaded one phase ahead
+  load_kstep<KT>(edge_block(node), 0, x0);
 
   STAMP_DECL;
   for (; node < Nend; node += stride) {
     const int nxt = (node + stride < Nend) ? node + stride : Nend - 1;  // tail: harmless re-load of a valid residue
-    LAUNDER(b2);
     STAMP(7);
     f32x4 p[MPNN_NT];  // P_i: needed only after layer 1
     {
@@ -194,8 +256,7 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t) p[t] = row_tile(Pi, t);
     }
-    const int node_e = (DEC && node >= enc_mod) ? node % enc_mod : node;
-    layer1_stream<KT>(W1s, hE + (size_t)node_e * (MPNN_NT * KT * 64) + lane, lane, h1);
+    layer1_stream<KT>(W1s, edge_block(node), lane, h1, x0);
     STAMP(0);
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
@@ -218,11 +279,11 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
     f32x4 y[MPNN_NT][KT];
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + 16 * t + 4 * g);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(b2s + 16 * t + 4 * g);
 #pragma unroll
       for (int c = 0; c < KT; ++c) y[t][c] = bb;
     }
-    split_gemm<KT, NKK, 0, MPNN_NT>(W2s, lane, hb, y);
+    lds_gemm<KT>(W2s, lane, hb, y);
     STAMP(2);
     if (SAVE) {
       f32x4* o = sv2 + (size_t)node * (MPNN_NT * KT * 64) + lane;
@@ -231,12 +292,13 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 #pragma unroll
         for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(y[t][c], &o[(t * KT + c) * 64]);
     }
-    // h1 is free: gather the next residue's rows under the GELU + reduction below
+    // h1 is free: gather the next residue's rows under the GELU + reduction below; its first hE k-step follows once
+    // half of y has been reduced (registers)
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
       for (int c = 0; c < KT; ++c) h1[t][c] = row_tile(rown[c], t);
-    reduce_store<KT>(y, w, gsum + (size_t)node * MPNN_H, lane);
+    reduce_store<KT>(y, w, gsum + (size_t)node * MPNN_H, lane, [&]() { load_kstep<KT>(edge_block(nxt), 0, x0); });
     if (!DEC) {
       float csum = 0.f;
 #pragma unroll
@@ -257,9 +319,16 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 // ---------------------------------------------------------------------------
 // encoder edge update, in place on hE (reference :90-95; unmasked):
 //   e_ik <- LN3(e_ik + W13 gelu(W12 gelu(P'_i + Q'_j + W11b e_ik) + b12) + b13)
-// W11b, W12 in LDS; W13 streams from L2 (A fragments three steps ahead of their MFMAs).
+// LDS (all 160 KiB): W11b and W12 (f16 hi + lo, 64 KiB each), the hi halves of W13's first W3_LDS_FRAGS fragments
+// (30 KiB) and the four parameter vectors b12, b13, ln_w, ln_b (2 KiB).  What streams from L2 is W13's lo halves
+// (32 KiB per residue instead of 64) through a register ring MPNN_UPD_RING steps ahead of their MFMAs, plus the hi
+// halves of the last two fragments.
+// Order of a wave's vector-memory operations matters (they complete in issue order): the next residue's first hE
+// k-step and its gathered rows are issued BEFORE the epilogue's stores, and nothing the epilogue waits for is issued
+// behind them (the parameter vectors come from LDS).
 // ---------------------------------------------------------------------------
 // SAVE (training forward): out of place (hE_out), and a1', a2' and the pre-LayerNorm sum z are written out.
+constexpr int W3_LDS_FRAGS = 30;  // of the NKK * 8 = 32 (to, kk) fragments of W13, in step order q = kk * 8 + to
 template <int KT, bool SAVE>
 __global__ void __launch_bounds__(MPNN_UPD_WAVES * 64)
 k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp, int offP,
@@ -269,12 +338,28 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
                   const float* __restrict__ ln_w, const float* __restrict__ ln_b, int N, int L,
                   f32x4* __restrict__ hE_out, f32x4* __restrict__ sv1, f32x4* __restrict__ sv2,
                   f32x4* __restrict__ svz, unsigned drop_thresh, unsigned drop_seed, float inv_keep) {
-  __shared__ h8 lds[2 * WSPLIT];
+  __shared__ h8 lds[2 * WSPLIT + W3_LDS_FRAGS * 64];
+  __shared__ __align__(16) float prm[4 * MPNN_H];
   lds_fill(lds, W11b, WSPLIT);
   lds_fill(lds + WSPLIT, W12, WSPLIT);
+  for (int i = threadIdx.x; i < W3_LDS_FRAGS * 64; i += blockDim.x) {
+    const int q = i >> 6, ln = i & 63;
+    lds[2 * WSPLIT + i] = W13[(((q & 7) * NKK + (q >> 3)) * 2 + 0) * 64 + ln];
+  }
+  for (int i = threadIdx.x; i < MPNN_H; i += blockDim.x) {
+    prm[i] = b12[i];
+    prm[MPNN_H + i] = b13[i];
+    prm[2 * MPNN_H + i] = ln_w[i];
+    prm[3 * MPNN_H + i] = ln_b[i];
+  }
   __syncthreads();
   const h8* W1s = lds;
   const h8* W2s = lds + WSPLIT;
+  const h8* W3s = lds + 2 * WSPLIT;
+  const float* b12s = prm;
+  const float* b13s = prm + MPNN_H;
+  const float* lnws = prm + 2 * MPNN_H;
+  const float* lnbs = prm + 3 * MPNN_H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, col = lane & 15;
   constexpr int Kp = KT * 16;
@@ -282,6 +367,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
   const int stride = rr.stride, Nend = rr.end;
   int node = rr.first;
   if (node >= Nend) return;
+  if (MPNN_STAGGER && __builtin_amdgcn_readfirstlane(wave) >= MPNN_UPD_WAVES / 2) __builtin_amdgcn_s_sleep(MPNN_STAGGER);
 
   auto setup = [&](int nd, const float* (&row)[KT]) {
     const int b = nd / L;
@@ -292,6 +378,10 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 
   const float* row[KT];
   setup(node, row);
+  f32x4 x0[2][KT];  // k-step 0 of the residue's hE, always loaded one phase ahead
+#if MPNN_UPD_X0
+  load_kstep<KT>(hE + (size_t)node * (MPNN_NT * KT * 64) + lane, 0, x0);
+#endif
   f32x4 h2[MPNN_NT][KT];  // carries the next residue's gathered Q' rows across iterations
 #pragma unroll
   for (int t = 0; t < MPNN_NT; ++t)
@@ -302,10 +392,6 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
   for (; node < Nend; node += stride) {
     const int nxt = (node + stride < Nend) ? node + stride : Nend - 1;
     STAMP(7);
-    LAUNDER(b12);
-    LAUNDER(b13);
-    LAUNDER(ln_w);
-    LAUNDER(ln_b);
     const h8* W3u = W13;
     LAUNDER(W3u);
     const h8* W3g = W3u + lane;
@@ -321,7 +407,11 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
       for (int c = 0; c < KT; ++c) h1[t][c] = h2[t][c];
+#if MPNN_UPD_X0
+    layer1_stream<KT>(W1s, x, lane, h1, x0);
+#else
     layer1_stream<KT>(W1s, x, lane, h1);
+#endif
     STAMP(0);
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
@@ -342,11 +432,11 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
     // ---- layer 2
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(b12 + 16 * t + 4 * g);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(b12s + 16 * t + 4 * g);
 #pragma unroll
       for (int c = 0; c < KT; ++c) h2[t][c] = bb;
     }
-    split_gemm<KT, NKK, 0, MPNN_NT>(W2s, lane, hb, h2);
+    lds_gemm<KT>(W2s, lane, hb, h2);
     STAMP(2);
     if (SAVE) {
 #pragma unroll
@@ -354,6 +444,21 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #pragma unroll
         for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(h2[t][c], &sv2[soff + (t * KT + c) * 64]);
     }
+    // W13 stream: lo halves (and the hi halves of the fragments that do not fit into LDS), D steps ahead
+    constexpr int D = MPNN_UPD_RING;
+    constexpr int NQ = NKK * MPNN_NT;
+    h8 al[D + 1], ahx[NQ - W3_LDS_FRAGS];
+    auto w3_load = [&](int qn) {
+      const int f = ((qn & 7) * NKK + (qn >> 3)) * 2;
+#ifndef MPNN_FAST
+      al[qn % (D + 1)] = W3g[(f + 1) * 64];
+#endif
+      if (qn >= W3_LDS_FRAGS) ahx[qn - W3_LDS_FRAGS] = W3g[f * 64];
+    };
+#ifndef MPNN_ABL_W3LDS
+#pragma unroll
+    for (int q = 0; q < D; ++q) w3_load(q);
+#endif
     // residual e -> layer 3's initial accumulator (loads fly under the GELU + split of h2); the training form
     // adds it after the dropout of the MLP output instead
 #pragma unroll
@@ -366,43 +471,36 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #endif
     tile_to_bfrag<MPNN_NT, KT, true>(h2, hb);
     STAMP(3);
-    // ---- layer 3; W13 fragments (hi, lo) from L2, D steps ahead.  step q = kk * 8 + to
+    // ---- layer 3.  step q = kk * 8 + to
 #ifdef MPNN_ABL_W3LDS  // timing-only ablation build: never shipped
     split_gemm<KT, NKK, 0, MPNN_NT>(W2s, lane, hb, h1);
 #else
-    {
-      constexpr int D = MPNN_UPD_RING;
-      h8 ah[D + 1], al[D + 1];
 #pragma unroll
-      for (int q = 0; q < D; ++q) {
-        ah[q] = W3g[(((q & 7) * NKK + (q >> 3)) * 2 + 0) * 64];
-        al[q] = W3g[(((q & 7) * NKK + (q >> 3)) * 2 + 1) * 64];
+    for (int kk = 0; kk < NKK; ++kk) {
+#pragma unroll
+      for (int to = 0; to < MPNN_NT; ++to) {
+        const int q = kk * MPNN_NT + to, qn = q + D;
+        if (qn < NQ) w3_load(qn);
+        h8 a_hi;
+        if (q < W3_LDS_FRAGS) a_hi = W3s[q * 64 + lane];
+        else a_hi = ahx[q - W3_LDS_FRAGS];
+#pragma unroll
+        for (int c = 0; c < KT; ++c) h1[to][c] = mfma_split(a_hi, al[q % (D + 1)], hb[kk][c], h1[to][c]);
       }
-#pragma unroll
-      for (int kk = 0; kk < NKK; ++kk) {
-#pragma unroll
-        for (int to = 0; to < MPNN_NT; ++to) {
-          const int q = kk * MPNN_NT + to, qn = q + D;
-          if (qn < NKK * MPNN_NT) {
-            ah[qn % (D + 1)] = W3g[(((qn & 7) * NKK + (qn >> 3)) * 2 + 0) * 64];
-            al[qn % (D + 1)] = W3g[(((qn & 7) * NKK + (qn >> 3)) * 2 + 1) * 64];
-          }
-#pragma unroll
-          for (int c = 0; c < KT; ++c) h1[to][c] = mfma_split(ah[q % (D + 1)], al[q % (D + 1)], hb[kk][c], h1[to][c]);
-        }
-        FENCE();
-      }
+      FENCE();
     }
 #endif
     STAMP(4);
-    // next residue's Q' rows -> h2 (carried to the next iteration), under LayerNorm + store
+    // next residue's Q' rows -> h2 (carried to the next iteration), under the LayerNorm
+#if !MPNN_UPD_ROWS
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
       for (int c = 0; c < KT; ++c) h2[t][c] = row_tile(rown[c], t);
+#endif
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(b13 + 16 * t + 4 * g);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(b13s + 16 * t + 4 * g);
 #pragma unroll
       for (int c = 0; c < KT; ++c) {
         h1[t][c] += bb;
@@ -414,17 +512,34 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
         }
       }
     }
-#ifndef MPNN_ABL_NOLN
-    tile_layernorm<KT>(h1, ln_w, ln_b, lane);
+    // LayerNorm statistics; then the next residue's first hE k-step is issued - BEFORE this residue's stores (vector
+    // memory operations complete in issue order) - and the tiles are normalised and stored one by one
+    float mean[KT], rstd[KT];
+    tile_layernorm_stats<KT>(h1, mean, rstd);
+#if MPNN_UPD_X0
+    load_kstep<KT>(hE + (size_t)nxt * (MPNN_NT * KT * 64) + lane, 0, x0);
 #endif
-    f32x4* xo = SAVE ? hE_out + soff : x;
-#ifdef MPNN_ABL_NOSTORE
-    if (h1[0][0].x == 1234.5f)
-#endif
+#if MPNN_UPD_ROWS
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
+      for (int c = 0; c < KT; ++c) h2[t][c] = row_tile(rown[c], t);
+#endif
+    f32x4* xo = SAVE ? hE_out + soff : x;
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+#ifndef MPNN_ABL_NOLN
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(lnws + 16 * t + 4 * g);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(lnbs + 16 * t + 4 * g);
+#pragma unroll
+      for (int c = 0; c < KT; ++c) h1[t][c] = (h1[t][c] - mean[c]) * rstd[c] * gm + bt;
+#endif
+#ifdef MPNN_ABL_NOSTORE
+      if (h1[0][0].x == 1234.5f)
+#endif
+#pragma unroll
       for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(h1[t][c], &xo[(t * KT + c) * 64]);
+    }
     STAMP(5);
   }
   STAMP_FLUSH(8);
