@@ -61,26 +61,54 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 PEAK_F32_MFMA_TFLOPS = 157.3   # for reference: the f32-input MFMA / f32 vector peak
 
 
-def cpu_baseline(B_cpu, L, K, iters):
+def host_cpu_info():
+    """(model string, physical cores of the machine, hardware threads of the machine, threads this process may use)."""
+    model, cores, phys = "unknown", set(), None
+    try:
+        pid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model == "unknown":
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                pid = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                cores.add((pid, ln.split(":", 1)[1].strip()))
+        phys = len(cores) or None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = logical
+    # the GPU box hands a one-GPU job a share of the host (OMP_NUM_THREADS is set to it): never oversubscribe that share
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    usable = min(allowed, share) if share > 0 else allowed
+    return model, phys or logical, logical, max(1, usable)
+
+
+def cpu_baseline(B_cpu, L, K, iters, warm=3):
     """The oracle in the reference's formulation (same [B,L,L] temporaries and O(L^3) mask einsum), timed on this
-    host's cores: forward at all (<= 16) threads (the headline `value`), forward on one thread, and one training step
-    (forward + autograd backward; the optimizer is negligible) at all threads.  Bounded samples, ~20 s in total."""
+    host's cores (>= 3 warm-up + >= 5 timed, median): forward on every core this job may use (the headline
+    `value`), forward on one thread, one training step (forward + autograd backward), and the C1 workload (100
+    synthetic chains, log-normal lengths, token-budget batches).  Bounded samples, ~25 s in total."""
     from mpnn_amd import ProteinMPNN
     from mpnn_amd.synthetic import synthetic_batch
     from oracle import mpnn_oracle as orc
 
-    threads = min(16, os.cpu_count() or 1)
+    cpu_model, phys, logical, threads = host_cpu_info()
     model = ProteinMPNN(k_neighbors=K, augment_eps=0.0, dropout=0.0).eval()
     sd = {k: v.detach() for k, v in model.state_dict().items()}
     cfg = orc.Config(k_neighbors=K)
 
-    def fwd_time(nthreads, Bc, n):
+    def fwd_time(nthreads, Bc, n, nwarm):
         torch.set_num_threads(nthreads)
         b = synthetic_batch(Bc, L, seed=123)
         args = (b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
         times = []
         with torch.no_grad():
-            orc.forward(sd, cfg, *args, fix_order=b["fix_order"], formulation="reference")  # warm-up
+            for _ in range(nwarm):
+                orc.forward(sd, cfg, *args, fix_order=b["fix_order"], formulation="reference")
             for _ in range(n):
                 t0 = time.perf_counter()
                 orc.forward(sd, cfg, *args, fix_order=b["fix_order"], formulation="reference")
@@ -106,18 +134,60 @@ def cpu_baseline(B_cpu, L, K, iters):
         times.sort()
         return times[len(times) // 2]
 
-    med = fwd_time(threads, B_cpu, iters)
-    one = fwd_time(1, 1, 2)
-    trn = train_time(threads, 1, 2)
+    med = fwd_time(threads, B_cpu, iters, warm)
+    one = fwd_time(1, 1, 3, 1)
+    trn = train_time(threads, 1, 3)
     torch.set_num_threads(threads)
+    c1 = c1_workload()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for b in c1["batches"]:
+            orc.forward(sd, cfg, b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"],
+                        fix_order=b["fix_order"], formulation="reference")
+    c1_s = time.perf_counter() - t0
     return {"value": B_cpu * L / med, "unit": "residues/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (reference formulation, fp32, torch CPU) forward on B={B_cpu} x L={L}, k={K}: "
-                      f"median of {iters} runs after 1 warm-up, {med * 1e3:.0f} ms each",
+            "cpu_model": cpu_model, "host_physical_cores": phys, "host_hardware_threads": logical,
+            "sample": f"oracle (reference formulation, fp32, torch CPU, {threads} threads = every core this job may use "
+                      f"of the host's {phys} physical cores) forward on B={B_cpu} x L={L}, k={K}: median of {iters} "
+                      f"runs after {warm} warm-ups, {med * 1e3:.0f} ms each",
             "forward_single_thread": {"value": round(L / one, 1), "cores": 1,
-                                      "sample": f"same, B=1 x L={L}, median of 2, {one * 1e3:.0f} ms each"},
+                                      "sample": f"same, B=1 x L={L}, median of 3 after 1 warm-up, {one * 1e3:.0f} ms each"},
             "train_step": {"value": round(L / trn, 1), "cores": threads,
-                           "sample": f"forward + loss_smoothed + autograd backward, B=1 x L={L}, median of 2, "
-                                     f"{trn * 1e3:.0f} ms each"}}
+                           "sample": f"forward + loss_smoothed + autograd backward, B=1 x L={L}, median of 3 after 1 "
+                                     f"warm-up, {trn * 1e3:.0f} ms each"},
+            "c1_forward": {"value": round(c1["residues"] / c1_s, 1), "unit": "valid residues/s", "cores": threads,
+                           "sample": f"BASELINE configs[0] stand-in: {c1['describe']}; one pass, {c1_s:.1f} s"}}
+
+
+def c1_workload(device="cpu", n_chains=100, budget=10000, seed=77):
+    """BASELINE configs[0]: ~100 chains with log-normal lengths (median 250, clipped to 40..1000) standing
+    in for the unavailable pdb_2021aug02_sample, grouped into padded batches under a 10000-token budget exactly as the
+    reference's StructureLoader does (protein_mpnn_dataset.py:60-87; the entry that closes a batch is kept here)."""
+    import numpy as np
+
+    from mpnn_amd.data import TokenBudgetBatcher
+    from mpnn_amd.synthetic import hash_normal, synthetic_batch
+
+    lengths = np.clip(np.exp(np.log(250.0) + 0.6 * hash_normal(n_chains, seed)), 40, 1000).astype(np.int64)
+    groups = [g for g in TokenBudgetBatcher(lengths, batch_size=budget, shuffle=False, drop_overflow=False).clusters if g]
+    batches = []
+    for gi, ids in enumerate(groups):
+        ls = [int(lengths[i]) for i in ids]
+        batches.append(synthetic_batch(len(ids), max(ls), seed=seed * 100 + gi, lengths=ls, device=device))
+    return {"batches": batches, "residues": int(lengths.sum()), "padded": int(sum(b["mask"].numel() for b in batches)),
+            "describe": f"{n_chains} synthetic chains, log-normal lengths (median 250, 40..1000; {int(lengths.sum())} "
+                        f"residues), {len(batches)} token-budget batches <= {budget} padded residues, k=48"}
+
+
+def library_sha256():
+    """Hash of the kernel library in use: PMC traffic numbers are only quoted for the build they were collected on."""
+    import hashlib
+
+    from mpnn_amd import _lib
+    try:
+        return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+    except OSError:
+        return None
 
 
 def max_over_ranks(x, dev, dist):
@@ -450,14 +520,15 @@ def main():
     dk = per_kernel[dominant]
     roofline = None
     traffic = None
-    try:  # HBM bytes per launch from the committed PMC passes (same workload only); see profiles/r01_pmc_traffic.txt
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if pm["workload"] == {"B": B, "L": L, "K": K} and dominant in pm["kernels"]:
+    try:  # HBM bytes per launch from the committed PMC passes: only for the same workload AND the same library build
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if (pm["workload"] == {"B": B, "L": L, "K": K} and dominant in pm["kernels"]
+                and pm.get("library_sha256") == library_sha256()):
             kk = pm["kernels"][dominant]
             traffic = {"bytes_per_launch": int((2 * kk["FETCH_SIZE_KB"] + kk["WRITE_SIZE_KB"]) * 1024),
                        "algorithmic_bytes_per_launch": 2 * B * L * 8 * ((K + 15) // 16) * 1024 if "update" in dominant
                        else B * L * 8 * ((K + 15) // 16) * 1024,
-                       "source": pm["source"], "correction": pm["correction"]}
+                       "source": pm["source"], "correction": pm["correction"], "library_sha256": pm["library_sha256"]}
     except (OSError, KeyError, ValueError):
         pass
     if dominant in FLOP_AS_WRITTEN:
@@ -465,12 +536,14 @@ def main():
         ach = FLOP_F16_ISSUED[dominant] * B * L / sec / 1e12
         asw = FLOP_AS_WRITTEN[dominant] * B * L / sec / 1e12
         roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": PEAK_F16_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4),
+                    "useful_frac": round(ach / 3.0 / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_ms": round(dk["avg_ms"], 4),
                     "as_written_f32_tflops": round(asw, 2),
                     "as_written_vs_f32_mfma_peak": round(asw / PEAK_F32_MFMA_TFLOPS, 4),
                     "note": "achieved = f16 MFMA FLOPs the kernel issues (3 split products per fp32 product; "
                             "per-edge 128x128 terms only) / HIP-event launch time, against the dense f16 MFMA peak; "
+                            "useful_frac = the fp32-equivalent FLOPs executed (a third of the issued ones) / same peak; "
                             "as_written = the reference's fp32 FLOPs for the op this launch replaces / same time. "
                             "The kernel is VALU-issue bound (GELU + f16 splitting do not co-issue with MFMA here), "
                             "see DESIGN.md section 4"}
@@ -532,6 +605,29 @@ def main():
                   "bit_identical": bool(torch.equal(rates["shared"][1], rates["repeated"][1])),
                   "note": "featurizer + encoder once per distinct structure (mpnn_dec_message_shared); SURVEY 8f N2"}
     log("shared-structure leg done")
+    # ---- secondary: BASELINE configs[0] stand-in (C1): ragged token-budget batches of 100 chains, forward only
+    c1 = None
+    if not a.no_f16_leg:
+        w = c1_workload(device=dev)
+
+        def c1_pass():
+            with torch.no_grad():
+                for bb in w["batches"]:
+                    o = model(bb["X"], bb["S"], bb["mask"], bb["chain_M"], bb["residue_idx"], bb["chain_encoding_all"],
+                              fix_order=bb["fix_order"])
+            return o
+        c1_pass()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            o = c1_pass()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / 5
+        c1 = {"workload": w["describe"], "valid_residues_per_s": round(w["residues"] / dt, 1),
+              "padded_residues_per_s": round(w["padded"] / dt, 1), "ms_per_pass": round(dt * 1e3, 3),
+              "note": "per rank; the CPU side of the same workload is cpu_baseline.c1_forward"}
+        assert torch.isfinite(o).all()
+    log("C1 leg done")
     train = None
     if a.train_batch > 0:
         train = train_leg(a, dev, rank, world, dist, barrier, _lib)
@@ -563,6 +659,7 @@ def main():
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(per_kernel.items())},
             "kernel_rooflines": kernel_rooflines,
             "shared_structure": shared,
+            "c1_forward": c1,
         }
         line["forward_f16_products"] = dict(f16, note="per-rank; one f16 MFMA product per fp32 product instead of three; "
                                             "fp32 accumulate / GELU / LayerNorm; tolerance in include/mpnn_hip.h")
@@ -573,7 +670,7 @@ def main():
         if not a.no_f16_leg:
             line["batch_assembly"] = assembly_leg(a, dev, with_cpu=not a.no_cpu_baseline and world == 1)
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(2, L, K, iters=3)
+            line["cpu_baseline"] = cpu_baseline(2, L, K, iters=5, warm=3)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:

@@ -57,6 +57,16 @@ int mpnn_pack_linear_split(const float* W, int out_f, int in_f, int ld, int col0
  * mode 1: y = hi + lo of the f16 hi/lo operand split that feeds the MFMAs (|x - y| <= 2^-21 |x| for 6e-5 < |x| < 65504). */
 int mpnn_probe_elementwise(const float* x, int n, int mode, float* y, void* stream);
 
+/* OPERAND RANGE of every entry point that takes "packed" weights or hE_frag (all edge / node / featurizer kernels):
+ * products run on the f16 matrix pipe, each fp32 operand split as f16 hi + f16 lo.  hi is a truncating conversion
+ * (saturates at 65504), lo = f16(x - hi) overflows to +-inf once |x| >= 131008, so an activation or weight beyond that
+ * turns the outputs into inf / NaN - never into a silently wrong finite number (fp32-class entry points; the *_f16
+ * twins drop lo and SATURATE silently at 65504).  Below 6e-5 an operand keeps 3e-8 ABSOLUTE resolution (f16
+ * subnormals), i.e. fewer than 22 significant bits.  mpnn_range_flag is the cheap device-side check the Python
+ * wrapper uses: weights at pack time against 65504, log_probs after a forward against +inf.
+ *   *flag |= bit if any x[i] is NaN or |x[i]| >= limit (limit = INFINITY: finiteness only).  No reference counterpart. */
+int mpnn_range_flag(const float* x, long long n, float limit, int32_t* flag, int bit, void* stream);
+
 /* PositionalEncodings as a table: table[d][p] = W[p][d] + bias[p]  (one_hot(d) @ W^T + b, :168-177). */
 int mpnn_pos_table(const float* W, const float* bias, int nbuckets /*66*/, int npos /*16*/, float* table,
                    void* stream);

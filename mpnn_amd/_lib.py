@@ -66,6 +66,7 @@ SIGNATURES = {
     "mpnn_mask_self": [_P, _I, _I, _P, _P],
     "mpnn_node_wgrad": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P],
     "mpnn_probe_elementwise": [_P, _I, _I, _P, _P],
+    "mpnn_range_flag": [_P, ctypes.c_longlong, _F, _P, _I, _P],
     "mpnn_node_wgrad_noalloc": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P],
 }
 

@@ -148,7 +148,23 @@ __global__ void k_probe(const float* __restrict__ x, int n, int mode, float* __r
     if (i8 + j < n) y[i8 + j] = v[j];
 }
 
+// *flag |= bit when any element is outside (-limit, limit) or is NaN (limit = +inf: a pure finiteness check)
+__global__ void k_range_flag(const float* __restrict__ x, long long n, float limit, int* __restrict__ flag, int bit) {
+  bool bad = false;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    bad |= !(fabsf(x[i]) < limit);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, bit);
+}
+
 }  // namespace
+
+extern "C" int mpnn_range_flag(const float* x, long long n, float limit, int32_t* flag, int bit, void* stream) {
+  MPNN_CHECK_ARG(x && flag && n > 0 && bit != 0, "mpnn_range_flag: bad arguments");
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_range_flag, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream, x, n,
+                     limit, flag, bit);
+  MPNN_LAUNCH_CHECK();
+}
 
 extern "C" int mpnn_probe_elementwise(const float* x, int n, int mode, float* y, void* stream) {
   MPNN_CHECK_ARG(x && y && n > 0 && (mode == 0 || mode == 1), "mpnn_probe_elementwise: bad arguments");

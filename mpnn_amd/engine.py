@@ -171,6 +171,80 @@ class PackedWeights:
         return tuple((p.data_ptr(), p._version, str(p.device)) for p in model.parameters())
 
 
+F16_MAX = 65504.0
+
+
+def check_weight_range(model):
+    """Every product on the path runs on the f16 matrix pipe with operands split as f16 hi + lo (include/mpnn_hip.h,
+    OPERAND RANGE): a weight of magnitude >= 65504 (or a non-finite one) cannot be represented.  Checked once per
+    packing, i.e. once per weight change - the only host synchronisation of the inference path, and none per call."""
+    ps = [p.detach() for p in model.parameters() if p.numel()]
+    if not ps:
+        return
+    amax = float(torch.stack(torch._foreach_norm(ps, float("inf"))).max())
+    if not (amax < F16_MAX):
+        raise RuntimeError(f"mpnn_amd: a parameter has magnitude {amax:.4g} (or is not finite); the MI355X kernels need "
+                           f"|w| < {F16_MAX:.0f} (operands are split into f16 hi + lo halves for the matrix pipe)")
+
+
+class NumericsGuard:
+    """Device-side overflow flag of one model.  After every forward / sampling call `mpnn_range_flag` ORs a bit into
+    the flag when a log-prob is inf / NaN - what an activation beyond the f16-split range (|x| >= 131008) turns into.
+    The flag travels to pinned host memory asynchronously; it is looked at without blocking at the start of the
+    model's next call (an overflow is then reported one call late) and with blocking by `check()`.  Nothing here
+    synchronises the stream on the hot path, and nothing is done while a HIP graph is being captured."""
+
+    SLOTS = 32
+
+    def __init__(self, dev):
+        self.flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.host = torch.zeros(self.SLOTS, dtype=torch.int32).pin_memory()
+        self.pending = []  # (event, slot, description)
+        self.next = 0
+
+    def watch(self, t, what):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        call("mpnn_range_flag", ptr(t), t.numel(), float("inf"), ptr(self.flag), 1, stream_ptr())
+        if len(self.pending) >= self.SLOTS:
+            self.poll(block=True)
+        slot = self.next
+        self.next = (self.next + 1) % self.SLOTS
+        self.host[slot:slot + 1].copy_(self.flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((ev, slot, what))
+
+    def poll(self, block=False):
+        if not self.pending or torch.cuda.is_current_stream_capturing():
+            return
+        bad = None
+        keep = []
+        for ev, slot, what in self.pending:
+            if block:
+                ev.synchronize()
+            if ev.query():
+                if int(self.host[slot]) != 0 and bad is None:
+                    bad = what
+            else:
+                keep.append((ev, slot, what))
+        self.pending = keep
+        if bad is not None:
+            self.flag.zero_()
+            self.pending = []
+            raise RuntimeError(f"mpnn_amd: {bad} produced inf / NaN log-probs: an activation or weight left the range of "
+                               "the f16-split matrix-pipe arithmetic (|x| < 65504, include/mpnn_hip.h OPERAND RANGE), or "
+                               "the inputs were not finite")
+
+
+def numerics_guard(model, dev) -> NumericsGuard:
+    g = model.__dict__.get("_numerics")
+    if g is None or g.flag.device != dev:
+        g = NumericsGuard(dev)
+        model.__dict__["_numerics"] = g
+    return g
+
+
 def invalidate_packed(model):
     """Drop every cached packed-weight set under `model`.  The cache key is (data_ptr, _version) per parameter, and
     torch's FUSED optimizers update parameters without touching `_version` (measured: AdamW(fused=True) leaves it
@@ -183,6 +257,7 @@ def invalidate_packed(model):
 def packed(model) -> PackedWeights:
     pw = getattr(model, "_packed", None)
     if pw is None or pw.key != PackedWeights.make_key(model):
+        check_weight_range(model)
         saved = _lib._suffix  # derived tables (TS) are always built with fp32-class products
         _lib._suffix = ""
         try:
@@ -315,6 +390,8 @@ def forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_ord
     """ProteinMPNN.forward (reference :427-529) on the HIP kernels, inference form (no autograd graph; the
     differentiable form is training.forward_train, which ProteinMPNN.forward picks in training mode)."""
     _require_device(X, "X")
+    guard = numerics_guard(model, X.device)
+    guard.poll()
     _lib.set_precision(getattr(model, "precision", "fp32"))
     try:
         X, mask, residue_idx, chain_encoding_all, n_struct = shared_structures(X, S, mask, residue_idx,
@@ -328,14 +405,18 @@ def forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_ord
                 fix_backbone_noise, noise_rows = fix_backbone_noise[:1].expand(n_struct, *fix_backbone_noise.shape[1:]), n_struct
             if (not model.training and not return_intermediates and model.features.top_k <= 48
                     and len(model.decoder_layers) > 0 and noise_rows in (None, n_struct)):
-                return _forward_shared(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order,
-                                       fix_backbone_noise)
+                out = _forward_shared(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order,
+                                      fix_backbone_noise)
+                guard.watch(out, "a forward call")
+                return out
             X, mask, residue_idx, chain_encoding_all = (_tile_rows(t, B) for t in
                                                         (X, mask, residue_idx, chain_encoding_all))
             if fix_backbone_noise is not None:
                 fix_backbone_noise = _tile_rows(fix_backbone_noise, B)
-        return _forward(model, X, S, mask, _tile_rows(chain_M, B), residue_idx, chain_encoding_all,
-                        _tile_rows(fix_order, B), fix_backbone_noise, return_intermediates)
+        out = _forward(model, X, S, mask, _tile_rows(chain_M, B), residue_idx, chain_encoding_all,
+                       _tile_rows(fix_order, B), fix_backbone_noise, return_intermediates)
+        guard.watch(out["log_probs"] if return_intermediates else out, "a forward call")
+        return out
     finally:
         _lib.set_precision("fp32")
 
@@ -584,10 +665,14 @@ def sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true=None
     teacher-forced forward on S with the same order returns them), order [n_samples,B,L]).  Residues with
     chain_M * mask == 0 are not designed: they keep S_true.  The featurizer and encoder run once per structure."""
     _require_device(X, "X")
+    guard = numerics_guard(model, X.device)
+    guard.poll()
     _lib.set_precision(getattr(model, "precision", "fp32"))
     try:
-        return _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_samples, temperature, seed,
-                       fix_order, logit_bias, backbone_noise)
+        out = _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_samples, temperature, seed,
+                      fix_order, logit_bias, backbone_noise)
+        guard.watch(out["log_probs"], "a sampling call")
+        return out
     finally:
         _lib.set_precision("fp32")
 

@@ -210,6 +210,15 @@ class ProteinMPNN(nn.Module):
         engine.invalidate_packed(self)
         return self
 
+    def check_numerics(self):
+        """Wait for the calls issued so far and raise RuntimeError if one of them produced inf / NaN log-probs (an
+        operand left the f16-split range of the matrix-pipe kernels, include/mpnn_hip.h OPERAND RANGE).  Without this
+        call the same error surfaces, one call late and without any host synchronisation, at the next forward."""
+        g = self.__dict__.get("_numerics")
+        if g is not None:
+            g.poll(block=True)
+        return self
+
     def sample(self, X, mask, chain_M, residue_idx, chain_encoding_all, S_true=None, n_samples=1, temperature=0.1,
                seed=0, fix_order=None, logit_bias=None):
         """Autoregressive sampling (no counterpart in the reference; see engine.sample)."""

@@ -77,12 +77,18 @@ def fill_parameters_(module: torch.nn.Module, seed: int = 0) -> None:
             p.copy_(torch.from_numpy(v.reshape(tuple(p.shape))).to(p.device, p.dtype))
 
 
-def synthetic_backbone(B: int, L: int, seed: int = 0) -> np.ndarray:
-    """Random-walk C-alpha trace (3.8 A steps, mild compaction) with N/C/O placed
+def synthetic_backbone(B: int, L: int, seed: int = 0, bond_jitter: float = 0.03) -> np.ndarray:
+    """Random-walk C-alpha trace (3.8 +- bond_jitter A steps, mild compaction) with N/C/O placed
     at ideal bond lengths (1.46 / 1.52 / 1.23 A) in a per-residue random frame.
     Returns float32 [B, L, 4, 3] in atom order N, CA, C, O.
+
+    The jitter (real CA-CA virtual bonds vary by about as much) keeps residues i-1 and i+1 from being
+    EXACTLY equidistant from i: with exact 3.8 A steps every row of the k-NN holds a near-tie whose order flips
+    with 1-ulp differences between sqrt implementations, and element-wise comparisons with the reference's
+    CPU-generated vectors had to skip most rows.
     """
     g = hash_normal(B * L * 3, seed * 11 + 1).reshape(B, L, 3).astype(np.float64)
+    steps = 3.8 + bond_jitter * hash_uniform(B * L, seed * 11 + 5).reshape(B, L).astype(np.float64)
     # persistent direction so the chain is locally extended but globally compact
     step = np.zeros_like(g)
     cur = g[:, 0] / (np.linalg.norm(g[:, 0], axis=-1, keepdims=True) + 1e-9)
@@ -91,7 +97,7 @@ def synthetic_backbone(B: int, L: int, seed: int = 0) -> np.ndarray:
     for i in range(L):
         cur = 0.6 * cur + 0.8 * g[:, i] - 0.002 * pos
         cur = cur / (np.linalg.norm(cur, axis=-1, keepdims=True) + 1e-9)
-        pos = pos + 3.8 * cur
+        pos = pos + steps[:, i:i + 1] * cur
         ca[:, i] = pos
         step[:, i] = cur
     f = hash_normal(B * L * 9, seed * 11 + 2).reshape(B, L, 3, 3).astype(np.float64)

@@ -164,9 +164,35 @@ def c2_checksum(ref):
     print("c2 checksum: sum", rec["lp_sum"])
 
 
+def state_dict_layout(ref):
+    """Key names, shapes and dtypes of the reference module's state_dict for the constructor variants that change
+    it (the checkpoint contract of train.py:548-568 / finetune.py:496-500), plus the parameter count."""
+    import json
+    variants = {
+        "default": dict(),
+        "train_py_defaults": dict(num_letters=21, node_features=128, edge_features=128, hidden_dim=128,
+                                  num_encoder_layers=3, num_decoder_layers=3, k_neighbors=48, dropout=0.1,
+                                  augment_eps=0.1),
+        "virtual_center": dict(use_virtual_center=True),
+        "occupancy": dict(occupancy_cutoff=8.0),
+        "cutoff_vc_occ": dict(edge_cutoff=15.0, use_virtual_center=True, occupancy_cutoff=6.0),
+        "two_plus_one_layers": dict(num_encoder_layers=2, num_decoder_layers=1),
+    }
+    out = {}
+    for name, kw in variants.items():
+        m = ref.ProteinMPNN(**kw)
+        sd = m.state_dict()
+        out[name] = {"kwargs": kw, "n_params": int(sum(p.numel() for p in m.parameters())),
+                     "keys": [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()]}
+    with open(os.path.join(HERE, "state_dict_layout.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("state_dict layout:", {k: (len(v["keys"]), v["n_params"]) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     ref = load_reference()
     for name, (mkw, bkw, extra) in CASES.items():
         run_case(ref, name, mkw, bkw, extra)
     training_case(ref)
     c2_checksum(ref)
+    state_dict_layout(ref)

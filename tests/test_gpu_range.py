@@ -1,0 +1,83 @@
+"""Operand range of the f16-split matrix-pipe arithmetic (include/mpnn_hip.h, OPERAND RANGE): large and tiny weights
+against the oracle, and the guards that turn an out-of-range operand into an error instead of silent garbage."""
+import pytest
+import torch
+
+from test_gpu_parity import LP_ATOL, LP_RTOL, assert_close, build_model, run_hip, run_oracle, same
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch():
+    from mpnn_amd.synthetic import synthetic_batch
+
+    b = synthetic_batch(B=2, L=72, seed=41, lengths=[72, 55], n_chains=2, design_fraction=0.6)
+    return {n: v.numpy() for n, v in b.items()}
+
+
+def _scale(model, pick, factor):
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if pick(n):
+                p.mul_(factor)
+    return model
+
+
+def test_layernorm_weights_times_50_match_the_oracle():
+    """Activations 50x the usual size (every LayerNorm gain x 50: |h_E|, |h_V| up to a few hundred, pre-activations in
+    the thousands): still inside the f16 range, and the split keeps fp32-class accuracy there."""
+    kw = dict(k_neighbors=48)
+    model = _scale(build_model(kw), lambda n: "norm" in n and n.endswith("weight"), 50.0)
+    rec = _batch()
+    out, ref = run_hip(model, rec), run_oracle(model, kw, rec)
+    same(out["E_idx"].cpu().numpy(), ref["E_idx"].numpy(), "E_idx")
+    m = rec["mask"].astype(bool)
+    big = float(ref["h_E_enc"][-1].abs().max())
+    assert big > 100.0, big
+    for l in range(3):   # tolerances relative to the 50x larger values
+        assert_close(out["h_V_enc"][l].cpu().numpy()[m], ref["h_V_enc"][l].numpy()[m], 1e-4, 50 * 5e-5, f"enc{l} h_V")
+    assert_close(out["log_probs"].cpu().numpy()[m], ref["log_probs"].numpy()[m], LP_RTOL, 10 * LP_ATOL, "log_probs")
+    model.check_numerics()
+
+
+def test_tiny_weights_match_the_oracle():
+    """Every matrix scaled to ~1e-6: operands far below the f16 normal range keep only 3e-8 ABSOLUTE resolution, which
+    is what matters for the sums they enter; log-probs stay within the usual bar of the oracle."""
+    kw = dict(k_neighbors=32)
+    model = _scale(build_model(kw), lambda n: n.endswith("weight") and "norm" not in n and "W_s" not in n, 1e-5)
+    rec = _batch()
+    out, ref = run_hip(model, rec), run_oracle(model, kw, rec)
+    m = rec["mask"].astype(bool)
+    assert_close(out["log_probs"].cpu().numpy()[m], ref["log_probs"].numpy()[m], LP_RTOL, LP_ATOL, "log_probs")
+    for l in range(3):
+        assert_close(out["h_V_dec"][l].cpu().numpy()[m], ref["h_V_dec"][l].numpy()[m], 1e-4, 5e-5, f"dec{l} h_V")
+
+
+def test_weight_beyond_f16_range_is_refused_when_packed():
+    model = build_model(dict(k_neighbors=16))
+    with torch.no_grad():
+        model.encoder_layers[1].W2.weight[3, 5] = 7.0e4
+    rec = _batch()
+    with pytest.raises(RuntimeError, match="65504"):
+        run_hip(model, rec, keep=False)
+    with torch.no_grad():
+        model.encoder_layers[1].W2.weight[3, 5] = float("nan")
+    with pytest.raises(RuntimeError):
+        run_hip(model, rec, keep=False)
+
+
+def test_activation_overflow_is_reported_not_silent():
+    """Weights in range, activations not (FFN output weights x 3e4 push h_V past 131008 before the LayerNorm): the
+    outputs are inf / NaN, and the wrapper says so - at check_numerics(), or one call late at the next forward."""
+    model = _scale(build_model(dict(k_neighbors=16)), lambda n: "dense.W_in.weight" in n or "W1.weight" in n, 2.0e3)
+    model = _scale(model, lambda n: "dense.W_out.weight" in n or n.endswith("W2.weight"), 2.0e3)
+    rec = _batch()
+    out = run_hip(model, rec, keep=False)
+    assert not bool(torch.isfinite(out).all()), "this model must overflow the f16-split range"
+    with pytest.raises(RuntimeError, match="inf / NaN"):
+        model.check_numerics()
+    model.check_numerics()                       # reported once, then clean
+    run_hip(model, rec, keep=False)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="inf / NaN"):
+        run_hip(model, rec, keep=False)          # the previous call's overflow surfaces here without a blocking wait

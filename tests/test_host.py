@@ -22,6 +22,53 @@ def test_state_dict_matches_reference_layout():
     assert sum(p.numel() for p in mpnn_amd.ProteinMPNN().parameters()) == 1660485
 
 
+def test_state_dict_matches_the_reference_generated_layout():
+    """Against key names / shapes / dtypes the REFERENCE module itself reported (tests/golden/state_dict_layout.json,
+    written by make_golden.py from model_utils.ProteinMPNN(**kwargs).state_dict()), in the reference's key order."""
+    import json
+
+    import mpnn_amd
+
+    layout = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_layout.json")))
+    assert len(layout) >= 6
+    for name, rec in layout.items():
+        m = mpnn_amd.ProteinMPNN(**rec["kwargs"])
+        got = [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()]
+        assert got == rec["keys"], name
+        assert sum(p.numel() for p in m.parameters()) == rec["n_params"], name
+
+
+def test_reference_format_checkpoint_loads(tmp_path):
+    """The reference saves {"epoch", "step", "num_edges", "noise_level", "model_state_dict", "optimizer_state_dict",
+    "scheduler_state_dict"} (train.py:548-568) and loads `ckpt["model_state_dict"]` (train.py:227), or a bare
+    state_dict (finetune.py:496-500).  Build such a file with the reference's key layout and load it strictly."""
+    import json
+
+    import mpnn_amd
+
+    layout = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_layout.json")))["train_py_defaults"]
+    g = torch.Generator().manual_seed(0)
+    sd = {k: torch.randn(shape, generator=g) for k, shape, _ in layout["keys"]}
+    opt_state = {"state": {}, "param_groups": [{"lr": 1e-3, "params": list(range(len(sd)))}]}
+    path = tmp_path / "last_epoch.pt"
+    torch.save({"epoch": 3, "step": 1234, "num_edges": 48, "noise_level": 0.1, "model_state_dict": sd,
+                "optimizer_state_dict": opt_state, "scheduler_state_dict": {}}, path)
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    model = mpnn_amd.ProteinMPNN(**layout["kwargs"])
+    res = model.load_state_dict(ckpt["model_state_dict"], strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    bare = tmp_path / "proteinmpnn.pt"                      # finetune.py also accepts the bare dict
+    torch.save(sd, bare)
+    model2 = mpnn_amd.ProteinMPNN(**layout["kwargs"])
+    model2.load_state_dict(torch.load(bare, map_location="cpu", weights_only=True))
+    assert torch.equal(model2.W_out.weight, sd["W_out.weight"])
+    # a checkpoint of a different variant must be refused, not silently accepted
+    with pytest.raises(RuntimeError):
+        mpnn_amd.ProteinMPNN(use_virtual_center=True).load_state_dict(sd)
+
+
 def test_library_exports_every_declared_symbol():
     from mpnn_amd import _lib
 

@@ -44,13 +44,20 @@ def test_oracle_matches_reference(name, formulation):
         np.testing.assert_array_equal(out["edge_mask"].numpy(), rec["edge_mask"])
     if "occupancy" in rec:
         np.testing.assert_allclose(out["occupancy"].numpy(), rec["occupancy"], rtol=1e-6, atol=1e-7)
-    # rows whose whole neighbour list is untied are comparable element-wise
-    row_ok = untied.all(-1) & mask
-    assert row_ok[mask].mean() > 0.03 or "c_ties" in name
+    # per-EDGE quantities (E depends only on which neighbour sits in the slot) are compared on every untied slot;
+    # per-NODE quantities on rows whose every slot is either untied or cut off (edge_mask = 0: beyond the cutoff the
+    # +1e6 penalty makes fp32 distances tie, but those edges are masked out of every message)
+    slot_ok = untied & mask[..., None]
+    cut = (rec["edge_mask"] == 0) if "edge_mask" in rec else np.zeros_like(untied)
+    row_ok = (untied | cut).all(-1) & mask
+    floor = 0.7 if "c_ties" in name else 0.9   # the synthetic backbones carry +-0.03 A bond jitter: no near-ties
+    assert row_ok[mask].mean() > floor, row_ok[mask].mean()
+    assert slot_ok[mask].mean() > 0.45, slot_ok[mask].mean()
     E_head = out["E"][:, :6].numpy()
-    sel = row_ok[:, :6]
+    sel = slot_ok[:, :6]
     np.testing.assert_allclose(E_head[sel], rec["E_head"][sel], rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(out["E"].double().sum(-1).numpy()[row_ok], rec["E_sum"][row_ok], atol=5e-5)
+    np.testing.assert_allclose(out["E"].double().sum(-1).numpy()[slot_ok], rec["E_sum"][slot_ok], atol=5e-5)
+    np.testing.assert_allclose(out["h_E0"].double().sum(-1).numpy()[slot_ok], rec["h_E0_sum"][slot_ok], atol=1e-4)
     for l in range(3):
         np.testing.assert_allclose(out["h_V_enc"][l].numpy()[row_ok], rec[f"enc{l}_h_V"][row_ok],
                                    rtol=1e-4, atol=2e-5)

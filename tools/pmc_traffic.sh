@@ -40,8 +40,10 @@ for k, cs in sorted(acc.items(), key=lambda kv: -sum(sum(v) for v in kv[1].value
     if name and name not in kern:
         kern[name] = {"FETCH_SIZE_KB": avg.get("FETCH_SIZE", 0.0), "WRITE_SIZE_KB": avg.get("WRITE_SIZE", 0.0)}
 open("gpurun_out/pmc_traffic.txt", "w").write("\n".join(lines) + "\n")
+import hashlib
 json.dump({"workload": {"B": 32, "L": 512, "K": 48},
-           "source": "profiles/r01_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes; tools/pmc_traffic.sh)",
+           "library_sha256": hashlib.sha256(open("mpnn_amd/libmpnn_hip.so", "rb").read()).hexdigest(),
+           "source": "profiles/pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes; tools/pmc_traffic.sh)",
            "correction": "bytes = 2 * FETCH_SIZE (gfx950 counts wide streaming reads at half) + WRITE_SIZE, KB -> bytes x 1024",
            "kernels": kern}, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
 print("\n".join(lines[:12]))
