@@ -143,13 +143,39 @@ int mpnn_dec_message_shared(const float* hE_frag, const float* PQ, int ldpq, int
  *   PQ[n, 128 p : 128 (p+1)] = Wproj_p h' + bproj_p,  p < nproj;
  *   if add_table: PQ[n, block add_block] += add_table[add_idx[n]][off_table : off_table+128]  (row stride ld_table;
  *   the decoder's per-letter sequence term W1c W_s[S_n], :478-479).
- * cnt == NULL uses cnt_const for every node (decoder: K).  do_update = 0 only projects hV_in. */
+ * cnt == NULL uses cnt_const for every node (decoder: K).  do_update = 0 only projects hV_in.
+ * do_update = 2 is PositionWiseFeedForward.forward on its own (:151-155): hV_out = W_out gelu(W_in hV_in + b_in) + b_out
+ * (only Win_packed / b_in / Wout_packed / b_out / hV_out are read; 128 -> 512 -> 128). */
 int mpnn_node_update(const float* hV_in, const float* gsum, const float* cnt, float cnt_const, const float* mask,
                      const float* W3_packed, const float* b3, const float* ln1_w, const float* ln1_b,
                      const float* Win_packed, const float* b_in, const float* Wout_packed, const float* b_out,
                      const float* ln2_w, const float* ln2_b, float scale, int do_update, const float* Wproj_packed,
                      const float* bproj, int nproj, const float* add_table, int ld_table, int off_table,
                      const int64_t* add_idx, int add_block, int n_nodes, float* hV_out, float* PQ, void* stream);
+
+/* The gather helpers of the reference as ONE indexed row copy (gather_edges :13-18, gather_nodes :21-30,
+ * gather_nodes_t :33-38, cat_neighbors_nodes :41-45):
+ *   out[(g * n_idx + q) * out_ld + out_col0 + c] = src[(g * n_src + idx[g * n_idx + q]) * C + c],  c < C, g < G
+ * gather_nodes: G = B, n_src = L, n_idx = L*K;  gather_nodes_t: n_idx = K;  gather_edges: G = B*L, n_src = L,
+ * n_idx = K;  cat_neighbors_nodes: out_ld = C_nb + C, out_col0 = C_nb (the neighbour features are copied into the
+ * leading columns by a second call with idx = NULL, which means idx = q).  C, out_ld, out_col0 multiples of 4;
+ * indices must be in [0, n_src) (the Python wrapper checks; out-of-range indices are clamped here, never followed). */
+int mpnn_gather_indexed(const float* src, const int64_t* idx, long long G, int n_src, long long n_idx, int C,
+                        float* out, int out_ld, int out_col0, void* stream);
+
+/* PositionalEncodings.forward (:168-177): E[e, :] = table[d_e], d = clip(offset + max_rel, 0, 2 max_rel) * mask +
+ * (1 - mask) * (2 max_rel + 1), table from mpnn_pos_table (row d = W[:, d] + bias: one_hot(d) @ W^T + b). */
+int mpnn_positional_encodings(const int64_t* offset, const int64_t* mask, long long n, int max_rel, const float* table,
+                              int npos, float* out, void* stream);
+
+/* y[r, 0:128] = sum_b W_b x[r, 128 b : 128 (b+1)] + bias: nn.Linear(in_f -> 128) over n_rows rows on the matrix pipe,
+ * in_f a multiple of 128, W_packed = in_f / 128 consecutive split-packed 128x128 blocks (mpnn_pack_linear_split of
+ * W[:, 128 b : 128 (b+1)]), bias may be NULL.  The per-edge term W1[:, 128:] h_ESV of the stand-alone DecLayer
+ * (:121-124) when the caller materialises the reference's [B,L,K,384] decoder input. */
+int mpnn_linear_rows(const float* x, int ldx, int in_f, const float* W_packed, const float* bias, long long n_rows,
+                     float* y, void* stream);
+int mpnn_linear_rows_f16(const float* x, int ldx, int in_f, const float* W_packed, const float* bias, long long n_rows,
+                         float* y, void* stream);
 
 /* occupancy_mlp (:414-421, :461-462): hV = LN(W2 gelu(w0 occ + b0) + b2). */
 int mpnn_occupancy_mlp(const float* occ, const float* w0, const float* b0, const float* W2_packed, const float* b2,

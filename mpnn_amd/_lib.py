@@ -65,6 +65,9 @@ SIGNATURES = {
     "mpnn_assemble_batch": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "mpnn_mask_self": [_P, _I, _I, _P, _P],
     "mpnn_node_wgrad": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P],
+    "mpnn_gather_indexed": [_P, _P, ctypes.c_longlong, _I, ctypes.c_longlong, _I, _P, _I, _I, _P],
+    "mpnn_positional_encodings": [_P, _P, ctypes.c_longlong, _I, _P, _I, _P, _P],
+    "mpnn_linear_rows": [_P, _I, _I, _P, _P, ctypes.c_longlong, _P, _P],
     "mpnn_probe_elementwise": [_P, _I, _I, _P, _P],
     "mpnn_range_flag": [_P, ctypes.c_longlong, _F, _P, _I, _P],
     "mpnn_node_wgrad_noalloc": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P],
@@ -72,7 +75,8 @@ SIGNATURES = {
 
 # reduced-precision twins (one f16 product per fp32 product) of the forward entry points: same signatures
 F16_ENTRIES = ("mpnn_edge_features", "mpnn_enc_message", "mpnn_enc_edge_update", "mpnn_dec_message", "mpnn_node_update",
-               "mpnn_dec_message_subset", "mpnn_node_update_subset", "mpnn_dec_message_shared", "mpnn_dec_layer_subset")
+               "mpnn_dec_message_subset", "mpnn_node_update_subset", "mpnn_dec_message_shared", "mpnn_dec_layer_subset",
+               "mpnn_linear_rows")
 for _n in F16_ENTRIES:
     SIGNATURES[_n + "_f16"] = SIGNATURES[_n]
 

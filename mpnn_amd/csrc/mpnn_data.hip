@@ -68,6 +68,59 @@ k_mask_self(const long long* __restrict__ chain_enc, int B, int L, float* __rest
 
 }  // namespace
 
+namespace {
+// one 16-byte piece of one gathered row per thread: consecutive threads walk a row, rows are 512 B in every call of
+// the model, so each wave-instruction moves four whole rows
+__global__ void k_gather_indexed(const float* __restrict__ src, const long long* __restrict__ idx, long long G, int n_src,
+                                 long long n_idx, int C4, float* __restrict__ out, int out_ld, int out_col0) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * n_idx * C4) return;
+  const int c = (int)(i % C4);
+  const long long row = i / C4, g = row / n_idx;
+  long long j = idx ? idx[row] : row - g * n_idx;
+  j = j < 0 ? 0 : (j >= n_src ? n_src - 1 : j);
+  const float4 v = reinterpret_cast<const float4*>(src + ((size_t)g * n_src + j) * (size_t)(4 * C4))[c];
+  *reinterpret_cast<float4*>(out + (size_t)row * out_ld + out_col0 + 4 * c) = v;
+}
+
+__global__ void k_positional_encodings(const long long* __restrict__ offset, const long long* __restrict__ mask,
+                                       long long n, int max_rel, const float* __restrict__ table, int npos,
+                                       float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * npos) return;
+  const long long e = i / npos;
+  const int p = (int)(i - e * npos);
+  long long d = offset[e] + max_rel;
+  d = d < 0 ? 0 : (d > 2 * max_rel ? 2 * max_rel : d);
+  const long long m = mask[e];
+  d = d * m + (1 - m) * (2 * max_rel + 1);
+  d = d < 0 ? 0 : (d > 2 * max_rel + 1 ? 2 * max_rel + 1 : d);  // a mask outside {0, 1} must not index out of the table
+  out[i] = table[d * npos + p];
+}
+}  // namespace
+
+extern "C" int mpnn_gather_indexed(const float* src, const int64_t* idx, long long G, int n_src, long long n_idx, int C,
+                                   float* out, int out_ld, int out_col0, void* stream) {
+  MPNN_CHECK_ARG(src && out, "mpnn_gather_indexed: null pointer");
+  MPNN_CHECK_ARG(G > 0 && n_src > 0 && n_idx > 0 && C > 0 && (C & 3) == 0 && (out_ld & 3) == 0 && (out_col0 & 3) == 0 &&
+                     out_col0 >= 0 && out_ld >= out_col0 + C && (idx || n_idx == n_src),
+                 "mpnn_gather_indexed: bad sizes (C, out_ld, out_col0 multiples of 4; idx == NULL needs n_idx == n_src)");
+  const long long total = G * n_idx * (C / 4);
+  MPNN_CHECK_ARG(total < (1LL << 31) * 256, "mpnn_gather_indexed: too many elements for one launch");
+  hipLaunchKernelGGL(k_gather_indexed, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     (const long long*)idx, G, n_src, n_idx, C / 4, out, out_ld, out_col0);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_positional_encodings(const int64_t* offset, const int64_t* mask, long long n, int max_rel,
+                                         const float* table, int npos, float* out, void* stream) {
+  MPNN_CHECK_ARG(offset && mask && table && out && n > 0 && max_rel >= 0 && npos > 0, "mpnn_positional_encodings: bad arguments");
+  const long long total = n * npos;
+  hipLaunchKernelGGL(k_positional_encodings, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)offset, (const long long*)mask, n, max_rel, table, npos, out);
+  MPNN_LAUNCH_CHECK();
+}
+
 extern "C" int mpnn_assemble_batch(const float* X_cat, const uint8_t* S_cat, const int32_t* chain_cat,
                                    const uint8_t* designed_cat, const int64_t* offsets, const int32_t* protein_ids,
                                    int B, int L_max, float* X, int64_t* S, float* mask, float* chain_M,

@@ -11,6 +11,8 @@ MPNN_KERNELS_BEGIN
 //   x   = LN1(h + dh);  y = LN2(x + W_out gelu(W_in x + b_in) + b_out);  h' = mask * y   (:82-88)
 //   PQ  = Wproj h' + bproj      (nproj blocks of 128 outputs: the next kernels' P/Q terms)
 // do_update = 0 skips the update and only projects h.
+// do_update = 2 is the position-wise feed-forward block on its own (PositionWiseFeedForward.forward, :151-155):
+//   hV_out = W_out gelu(W_in h + b_in) + b_out  - no W3 / LayerNorm / residual / mask.
 // The node level has little parallelism (N / 16 wave tiles) and ~0.8 MB of weights per layer, so the kernel
 // is a weight-streaming problem: the 9 + nproj packed 128x128 matrices (64 KiB each: W3, then W_in / W_out in
 // four hidden-unit quarters, then the projections) flow through a two-slot LDS ring by LDS-DMA
@@ -55,14 +57,17 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
   const int nd0 = live ? node : N - 1;
   const int nd = node_list ? node_list[nd0] : nd0;  // sampling: the launch covers a listed subset of residues
 
-  const int nmat = (do_update ? 9 : 0) + nproj;
+  const int nupd = do_update == 1 ? 9 : (do_update == 2 ? 8 : 0);
+  const int nmat = nupd + nproj;
   auto matrix = [&](int k) -> const h8* {
-    if (do_update) {
-      if (k == 0) return W3;
-      if (k < 9) return (((k - 1) & 1) ? Wout : Win) + (size_t)((k - 1) >> 1) * WSPLIT;
-      k -= 9;
+    if (k < nupd) {
+      if (do_update == 1) {
+        if (k == 0) return W3;
+        --k;
+      }
+      return ((k & 1) ? Wout : Win) + (size_t)(k >> 1) * WSPLIT;
     }
-    return Wproj + (size_t)k * WSPLIT;
+    return Wproj + (size_t)(k - nupd) * WSPLIT;
   };
   int k = 0;
   if (nmat > 0) stage_matrix(matrix(0), lds);
@@ -84,25 +89,30 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
     h[t][0] = *reinterpret_cast<const f32x4*>(hV_in + (size_t)nd * MPNN_H + 16 * t + 4 * g);
 
   if (do_update) {
-    f32x4 gs[MPNN_NT][1], dh[MPNN_NT][1];
-    const float cn = cnt ? cnt[nd] : cnt_const;
-#pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t) {
-      gs[t][0] = *reinterpret_cast<const f32x4*>(gsum + (size_t)nd * MPNN_H + 16 * t + 4 * g);
-      dh[t][0] = *reinterpret_cast<const f32x4*>(b3 + 16 * t + 4 * g) * cn;
-    }
     BFrag xb[NKK][1];
-    tile_to_bfrag<MPNN_NT, 1, false>(gs, xb);
-    prefetch();
-    split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT + lane, xb, dh);
-    retire();
+    if (do_update == 1) {
+      f32x4 gs[MPNN_NT][1], dh[MPNN_NT][1];
+      const float cn = cnt ? cnt[nd] : cnt_const;
 #pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t) h[t][0] = h[t][0] + dh[t][0] * inv_scale;
-    tile_layernorm<1>(h, ln1w, ln1b, lane);
+      for (int t = 0; t < MPNN_NT; ++t) {
+        gs[t][0] = *reinterpret_cast<const f32x4*>(gsum + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+        dh[t][0] = *reinterpret_cast<const f32x4*>(b3 + 16 * t + 4 * g) * cn;
+      }
+      tile_to_bfrag<MPNN_NT, 1, false>(gs, xb);
+      prefetch();
+      split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT + lane, xb, dh);
+      retire();
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t) h[t][0] = h[t][0] + dh[t][0] * inv_scale;
+      tile_layernorm<1>(h, ln1w, ln1b, lane);
+    }
     tile_to_bfrag<MPNN_NT, 1, false>(h, xb);
     f32x4 o[MPNN_NT][1];
 #pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t) o[t][0] = h[t][0] + *reinterpret_cast<const f32x4*>(bout + 16 * t + 4 * g);
+    for (int t = 0; t < MPNN_NT; ++t) {
+      o[t][0] = *reinterpret_cast<const f32x4*>(bout + 16 * t + 4 * g);
+      if (do_update == 1) o[t][0] += h[t][0];
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {  // FFN hidden units in quarters of 128
       f32x4 hid[MPNN_NT][1];
@@ -118,8 +128,11 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
       split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT + lane, hb, o);
       retire();
     }
-    tile_layernorm<1>(o, ln2w, ln2b, lane);
-    const float mk = mask[nd];
+    float mk = 1.0f;
+    if (do_update == 1) {
+      tile_layernorm<1>(o, ln2w, ln2b, lane);
+      mk = mask[nd];
+    }
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
       h[t][0] = o[t][0] * mk;
@@ -323,6 +336,39 @@ k_logits(const float* __restrict__ hV, const f32x4* __restrict__ Wp, const float
   }
 }
 
+// ---------------------------------------------------------------------------
+// y[r] = sum_b W_b x[r, 128 b : 128 (b+1)] + bias : a Linear(128 nb -> 128) over rows, one wavefront per 16 rows, the
+// packed 128x128 blocks streamed from L2 (each block is read once per wave: for the stand-alone DecLayer surface, where
+// the caller hands over the materialised [B,L,K,384] decoder input of the reference, :118-124)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_linear_rows(const float* __restrict__ x, int ldx, int nb, const h8* __restrict__ W, const float* __restrict__ bias,
+              long long n_rows, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int g = lane >> 4, col = lane & 15;
+  const long long row = tile * 16 + col;
+  if (tile * 16 >= n_rows) return;
+  const bool live = row < n_rows;
+  const float* xr = x + (size_t)(live ? row : n_rows - 1) * ldx + 4 * g;
+  f32x4 acc[MPNN_NT][1];
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t)
+    acc[t][0] = bias ? *reinterpret_cast<const f32x4*>(bias + 16 * t + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < nb; ++b) {
+    f32x4 h[MPNN_NT][1];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) h[t][0] = *reinterpret_cast<const f32x4*>(xr + 128 * b + 16 * t);
+    BFrag xb[NKK][1];
+    tile_to_bfrag<MPNN_NT, 1, false>(h, xb);
+    split_gemm_stream<1, NKK, MPNN_NT, 6>(W + (size_t)b * WSPLIT + lane, xb, acc);
+  }
+  if (live) {
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) *reinterpret_cast<f32x4*>(y + (size_t)row * MPNN_H + 16 * t + 4 * g) = acc[t][0];
+  }
+}
+
 MPNN_KERNELS_END
 
 // ===========================================================================
@@ -337,8 +383,10 @@ extern "C" int MPNN_API(mpnn_node_update)(const float* hV_in, const float* gsum,
                                 float scale, int do_update, const float* Wproj_packed, const float* bproj, int nproj,
                                 const float* add_table, int ld_table, int off_table, const int64_t* add_idx,
                                 int add_block, int n_nodes, float* hV_out, float* PQ, void* stream) {
-  MPNN_CHECK_ARG(hV_in && n_nodes > 0 && nproj >= 0, "mpnn_node_update: bad arguments");
-  if (do_update)
+  MPNN_CHECK_ARG(hV_in && n_nodes > 0 && nproj >= 0 && do_update >= 0 && do_update <= 2, "mpnn_node_update: bad arguments");
+  if (do_update == 2)
+    MPNN_CHECK_ARG(Win_packed && b_in && Wout_packed && b_out && hV_out, "mpnn_node_update: null pointer in the FFN-only form");
+  if (do_update == 1)
     MPNN_CHECK_ARG(gsum && mask && W3_packed && b3 && ln1_w && ln1_b && Win_packed && b_in && Wout_packed && b_out &&
                        ln2_w && ln2_b && hV_out && scale != 0.f,
                    "mpnn_node_update: null pointer in update");
@@ -349,9 +397,19 @@ extern "C" int MPNN_API(mpnn_node_update)(const float* hV_in, const float* gsum,
   hipLaunchKernelGGL(k_node_update, dim3(ceil_div(n_nodes, 16 * MPNN_NODE_WAVES)), dim3(64 * MPNN_NODE_WAVES), 0,
                      (hipStream_t)stream, hV_in, gsum, cnt,
                      cnt_const, mask, (const h8*)W3_packed, b3, ln1_w, ln1_b, (const h8*)Win_packed, b_in,
-                     (const h8*)Wout_packed, b_out, ln2_w, ln2_b, 1.0f / scale, do_update,
+                     (const h8*)Wout_packed, b_out, ln2_w, ln2_b, scale != 0.f ? 1.0f / scale : 0.f, do_update,
                      (const h8*)Wproj_packed, bproj, nproj, add_table, ld_table, off_table,
                      (const long long*)add_idx, add_block, n_nodes, hV_out, PQ, (const int*)nullptr);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int MPNN_API(mpnn_linear_rows)(const float* x, int ldx, int in_f, const float* W_packed, const float* bias,
+                                long long n_rows, float* y, void* stream) {
+  MPNN_CHECK_ARG(x && W_packed && y, "mpnn_linear_rows: null pointer");
+  MPNN_CHECK_ARG(n_rows > 0 && in_f >= 128 && in_f % 128 == 0 && ldx >= in_f && (ldx & 3) == 0,
+                 "mpnn_linear_rows: in_f must be a multiple of 128 and ldx a multiple of 4 floats");
+  hipLaunchKernelGGL(k_linear_rows, dim3((unsigned)((n_rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     in_f / 128, (const h8*)W_packed, bias, n_rows, y);
   MPNN_LAUNCH_CHECK();
 }
 

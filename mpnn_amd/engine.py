@@ -853,20 +853,74 @@ def enc_layer_standalone(layer, h_V, h_E, E_idx, mask_V=None, mask_attend=None):
 
 
 # ---------------------------------------------------------------------------
+# stand-alone PositionWiseFeedForward / PositionalEncodings surfaces (reference :151-155, :168-177)
+# ---------------------------------------------------------------------------
+def _pack_split_new(W, dev, col0=0, ncols=None):
+    W = _f32(W)
+    out_f, ld = W.shape
+    ncols = ld - col0 if ncols is None else ncols
+    out = torch.empty(((out_f + 15) // 16) * ((ncols + 31) // 32) * 512, device=dev, dtype=torch.float32)
+    call("mpnn_pack_linear_split", ptr(W), out_f, ncols, ld, col0, 0, ptr(out), stream_ptr())
+    return out
+
+
+def ffn_standalone(ffn, h_V):
+    _require_device(h_V, "h_V")
+    dev = h_V.device
+    if tuple(ffn.W_in.weight.shape) != (4 * H, H) or tuple(ffn.W_out.weight.shape) != (H, 4 * H):
+        raise ValueError("mpnn_amd.PositionWiseFeedForward runs 128 -> 512 -> 128 only (the reference's only use)")
+    key = tuple((p.data_ptr(), p._version) for p in ffn.parameters())
+    c = ffn.__dict__.get("_packed")
+    if c is None or c["key"] != key:
+        c = dict(key=key, Win=_pack_split_new(ffn.W_in.weight, dev), bin=_f32(ffn.W_in.bias),
+                 Wout=torch.cat([_pack_split_new(ffn.W_out.weight, dev, H * q, H) for q in range(4)]),
+                 bout=_f32(ffn.W_out.bias))
+        ffn.__dict__["_packed"] = c
+    x = _f32(h_V).reshape(-1, H)
+    n = x.shape[0]
+    out = torch.empty(n, H, device=dev, dtype=torch.float32)
+    if n:
+        call("mpnn_node_update", ptr(x), None, None, 0.0, None, None, None, None, None, ptr(c["Win"]), ptr(c["bin"]),
+             ptr(c["Wout"]), ptr(c["bout"]), None, None, 1.0, 2, None, None, 0, None, 0, 0, None, 0, n, ptr(out), None,
+             stream_ptr())
+    return out.view(*h_V.shape[:-1], H)
+
+
+def positional_encodings_standalone(pe, offset, mask):
+    _require_device(offset, "offset")
+    dev = offset.device
+    nb, npos = 2 * pe.max_relative_feature + 2, pe.num_embeddings
+    key = tuple((p.data_ptr(), p._version) for p in pe.parameters())
+    c = pe.__dict__.get("_table")
+    if c is None or c[0] != key:
+        table = torch.empty(nb * npos, device=dev, dtype=torch.float32)
+        Wl, bl = _f32(pe.linear.weight), _f32(pe.linear.bias)
+        call("mpnn_pos_table", ptr(Wl), ptr(bl), nb, npos, ptr(table), stream_ptr())
+        c = (key, table, (Wl, bl))
+        pe.__dict__["_table"] = c
+    off, m = _i64(offset), _i64(mask.expand_as(offset))
+    out = torch.empty(*offset.shape, npos, device=dev, dtype=torch.float32)
+    if off.numel():
+        call("mpnn_positional_encodings", ptr(off), ptr(m), off.numel(), pe.max_relative_feature, ptr(c[1]), npos,
+             ptr(out), stream_ptr())
+    return out
+
+
+# ---------------------------------------------------------------------------
 # stand-alone DecLayer surface (reference :118-138): h_ESV materialised by the caller, natural layouts
 # ---------------------------------------------------------------------------
 def dec_layer_standalone(layer, h_V, h_ESV, mask_V=None, mask_attend=None):
     """The fused decoder inside ProteinMPNN.forward never materialises h_ESV; this entry serves callers that do.
-    W1 [h_V_i | h_ESV_ik] = (W1a h_V_i + b1) + W1r h_ESV_ik: the per-edge term is one plain library GEMM
-    ([B L K, 384] x [384, 128]); its result takes the place of the edge tensor in the message kernel (identity as
-    the per-edge weight, no gathered row), then the shared node kernel finishes the layer."""
+    W1 [h_V_i | h_ESV_ik] = (W1a h_V_i + b1) + W1r h_ESV_ik: the per-edge term is mpnn_linear_rows (a Linear(384 -> 128)
+    over the B L K rows on the matrix pipe); its result takes the place of the edge tensor in the message kernel
+    (identity as the per-edge weight, no gathered row), then the shared node kernel finishes the layer."""
     _require_device(h_V, "h_V")
     dev = h_V.device
     B, L, K, C = h_ESV.shape
     N = B * L
     st = stream_ptr()
-    if K > 64 or C != layer.W1.weight.shape[1] - H:
-        raise ValueError("DecLayer: h_ESV must be [B, L, K <= 64, num_in]")
+    if K > 64 or C != layer.W1.weight.shape[1] - H or C % H:
+        raise ValueError("DecLayer: h_ESV must be [B, L, K <= 64, num_in], num_in a multiple of 128")
     key = tuple((p.data_ptr(), p._version) for p in layer.parameters())
     c = getattr(layer, "_packed", None)
     if c is None or c["key"] != key:
@@ -878,7 +932,8 @@ def dec_layer_standalone(layer, h_V, h_ESV, mask_V=None, mask_attend=None):
             call("mpnn_pack_linear_split", ptr(W), out_f, ncols, ld, col0, 0, ptr(out), st)
             return out
         c = dict(key=key, g1=(pack_split(layer.W1.weight, 0, H), _f32(layer.W1.bias), 1),
-                 eye=pack_split(torch.eye(H, device=dev)), Wr=_f32(layer.W1.weight[:, H:]),
+                 eye=pack_split(torch.eye(H, device=dev)),
+                 Wr=torch.cat([pack_split(layer.W1.weight, H * (1 + q), H) for q in range(C // H)]),
                  W2=pack_split(layer.W2.weight), b2=_f32(layer.W2.bias), W3=pack_split(layer.W3.weight),
                  b3=_f32(layer.W3.bias), ln1w=_f32(layer.norm1.weight), ln1b=_f32(layer.norm1.bias),
                  ln2w=_f32(layer.norm2.weight), ln2b=_f32(layer.norm2.bias), Win=pack_split(layer.dense.W_in.weight),
@@ -887,7 +942,8 @@ def dec_layer_standalone(layer, h_V, h_ESV, mask_V=None, mask_attend=None):
                  bout=_f32(layer.dense.W_out.bias), scale=float(layer.scale))
         layer._packed = c
     hV = _f32(h_V).view(N, H)
-    X = torch.matmul(_f32(h_ESV).view(N * K, C), c["Wr"].t())            # per-edge W1r h_ESV
+    X = torch.empty(N * K, H, device=dev, dtype=torch.float32)           # per-edge W1r h_ESV
+    call("mpnn_linear_rows", ptr(_f32(h_ESV).view(N * K, C)), C, C, ptr(c["Wr"]), None, N * K, ptr(X), st)
     hE = edges_from_natural(X.view(N, K, H), N, K)
     Kp = 16 * ((K + 15) // 16)
     idx32 = torch.arange(L, device=dev, dtype=torch.int32).view(1, L, 1).expand(B, L, Kp).contiguous()  # rows unused

@@ -32,7 +32,10 @@ class PositionWiseFeedForward(nn.Module):
         self.W_out = nn.Linear(num_ff, num_hidden, bias=True)
 
     def forward(self, h_V):
-        raise RuntimeError("PositionWiseFeedForward is fused into mpnn_node_update; call the owning layer")
+        """W_out(gelu(W_in(h_V)))   (reference :151-155).  Inside EncLayer / DecLayer the block is fused into
+        mpnn_node_update; called on its own it is that kernel's FFN-only form (128 -> 4 x 128 -> 128 only)."""
+        with _on_device_of(h_V), torch.autocast(device_type="cuda", enabled=False):
+            return engine.ffn_standalone(self, h_V)
 
 
 class PositionalEncodings(nn.Module):
@@ -45,7 +48,11 @@ class PositionalEncodings(nn.Module):
         self.linear = nn.Linear(2 * max_relative_feature + 1 + 1, num_embeddings)
 
     def forward(self, offset, mask):
-        raise RuntimeError("PositionalEncodings is fused into mpnn_edge_features; call ProteinFeatures")
+        """offset, mask: integer tensors of one shape -> [..., num_embeddings]   (reference :168-177): the one-hot
+        times Linear is a lookup in the 66-row table mpnn_pos_table builds.  Inside ProteinFeatures the lookup is
+        fused into mpnn_edge_features."""
+        with _on_device_of(offset), torch.autocast(device_type="cuda", enabled=False):
+            return engine.positional_encodings_standalone(self, offset, mask)
 
 
 class EncLayer(nn.Module):
