@@ -228,8 +228,9 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
         log("train: broadcasting parameters")
         distributed.broadcast_parameters(model.parameters())
         log("train: broadcast done")
-    # AdamW(lr, weight_decay=1e-2) as train.py:217; the fused multi-tensor implementation is the same update in one launch
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2, fused=True)
+    # AdamW(lr, weight_decay=1e-2) as train.py:217, on the in-tree multi-tensor kernel
+    from mpnn_amd.optim import AdamW
+    opt = AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2)   # mpnn_adamw_step: 3 launches for the 118 tensors
     b = synthetic_batch(B, L, seed=2000 + rank, device=dev)
     batch = (b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
     steps, warm = max(3, min(a.steps, 10)), 2
@@ -279,8 +280,8 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
                                  "4.3-4.5 TB/s, the weight-gradient pass at 3.6 TB/s (PMC-confirmed bytes)"},
             "final_loss": round(float(loss), 6),
             "hip_kernels_ms_per_step": kern, "hip_kernels_total_ms": round(hip_ms, 3),
-            "note": "forward, backward and weight gradients of the featurizer, edge and node stages, the output head "
-                    "and the smoothed loss are HIP kernels; sequence embedding and optimizer (fused AdamW) are ATen ops"}
+            "note": "forward, backward and weight gradients of the featurizer, edge and node stages, the output head, "
+                    "the smoothed loss and the AdamW update are HIP kernels; the sequence-embedding lookup is an ATen op"}
 
 
 def assembly_leg(a, dev, with_cpu):

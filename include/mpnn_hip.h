@@ -153,6 +153,20 @@ int mpnn_node_update(const float* hV_in, const float* gsum, const float* cnt, fl
                      const float* bproj, int nproj, const float* add_table, int ld_table, int off_table,
                      const int64_t* add_idx, int add_block, int n_nodes, float* hV_out, float* PQ, void* stream);
 
+/* Optimizer step of the reference's training loop (train.py:217 torch.optim.AdamW(lr, weight_decay=1e-2), :389-393
+ * clip_grad_norm_ then optimizer.step) for ALL parameter tensors in one launch per 48 tensors.
+ * params / grads / exp_avg / exp_avg_sq / numel are HOST arrays of n device pointers / element counts (fp32 tensors).
+ *   mpnn_grad_sumsq: sumsq[0] += sum of squares of every gradient element (zero sumsq first; device scalar).
+ *   mpnn_grad_scale: grads *= min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))       (torch.nn.utils.clip_grad_norm_)
+ *   mpnn_adamw_step: torch.optim.AdamW's update (decoupled weight decay, bias correction for `step` >= 1, no amsgrad);
+ *     when grad_sumsq != NULL and max_norm > 0 the clip coefficient above is applied to the gradients on the fly, so
+ *     clipping costs no extra pass over them and nothing synchronises with the host. */
+int mpnn_grad_sumsq(int n, const float* const* grads, const int* numel, float* sumsq, void* stream);
+int mpnn_grad_scale(int n, float* const* grads, const int* numel, const float* sumsq, float max_norm, void* stream);
+int mpnn_adamw_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const int* numel, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int step, const float* grad_sumsq, float max_norm, void* stream);
+
 /* The gather helpers of the reference as ONE indexed row copy (gather_edges :13-18, gather_nodes :21-30,
  * gather_nodes_t :33-38, cat_neighbors_nodes :41-45):
  *   out[(g * n_idx + q) * out_ld + out_col0 + c] = src[(g * n_src + idx[g * n_idx + q]) * C + c],  c < C, g < G

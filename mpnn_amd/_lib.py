@@ -67,6 +67,9 @@ SIGNATURES = {
     "mpnn_node_wgrad": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P],
     "mpnn_gather_indexed": [_P, _P, ctypes.c_longlong, _I, ctypes.c_longlong, _I, _P, _I, _I, _P],
     "mpnn_positional_encodings": [_P, _P, ctypes.c_longlong, _I, _P, _I, _P, _P],
+    "mpnn_grad_sumsq": [_I, _P, _P, _P, _P],
+    "mpnn_grad_scale": [_I, _P, _P, _P, _F, _P],
+    "mpnn_adamw_step": [_I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _F, _P],
     "mpnn_linear_rows": [_P, _I, _I, _P, _P, ctypes.c_longlong, _P, _P],
     "mpnn_probe_elementwise": [_P, _I, _I, _P, _P],
     "mpnn_range_flag": [_P, ctypes.c_longlong, _F, _P, _I, _P],

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <math.h>
 #include "mpnn_common.h"
 
 namespace {
@@ -148,6 +149,99 @@ __global__ void k_probe(const float* __restrict__ x, int n, int mode, float* __r
     if (i8 + j < n) y[i8 + j] = v[j];
 }
 
+// ---------------------------------------------------------------------------
+// Multi-tensor AdamW and gradient-norm clipping (reference train.py:217 AdamW(lr, weight_decay=1e-2), :389-393
+// clip_grad_norm_ + optimizer.step): every parameter tensor of the model in one launch per 48 tensors, the clip
+// coefficient read from device memory so the step never synchronises with the host.
+// ---------------------------------------------------------------------------
+constexpr int MT_MAX = 48;  // tensors per launch (the table travels as a kernel argument)
+struct MultiTensor {
+  float* p[MT_MAX];
+  const float* g[MT_MAX];
+  float* m[MT_MAX];
+  float* v[MT_MAX];
+  int numel[MT_MAX];
+  int n;
+};
+constexpr int MT_CHUNK = 2048;  // elements per workgroup
+
+// sumsq[0] += sum of squares of every gradient element (fp32 partials, one atomic per workgroup)
+__global__ void __launch_bounds__(256)
+k_grad_sumsq(MultiTensor t, float* __restrict__ sumsq) {
+  __shared__ float part[4];
+  const int ti = blockIdx.y, n = t.numel[ti];
+  const int i0 = blockIdx.x * MT_CHUNK;
+  if (i0 >= n) return;
+  const float* __restrict__ g = t.g[ti];
+  float s = 0.f;
+  for (int i = i0 + threadIdx.x; i < min(n, i0 + MT_CHUNK); i += 256) s += g[i] * g[i];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(sumsq, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+// torch.nn.utils.clip_grad_norm_: g *= min(1, max_norm / (sqrt(sumsq) + 1e-6))
+__device__ __forceinline__ float clip_coef(const float* sumsq, float max_norm) {
+  if (!sumsq || !(max_norm > 0.f)) return 1.0f;
+  const float c = max_norm / (sqrtf(*sumsq) + 1e-6f);
+  return c < 1.0f ? c : 1.0f;
+}
+
+__global__ void __launch_bounds__(256)
+k_grad_scale(MultiTensor t, const float* __restrict__ sumsq, float max_norm) {
+  const int ti = blockIdx.y, n = t.numel[ti];
+  const int i0 = blockIdx.x * MT_CHUNK;
+  if (i0 >= n) return;
+  const float c = clip_coef(sumsq, max_norm);
+  if (c == 1.0f) return;
+  float* g = t.p[ti];  // the gradient travels in the p slot for this kernel
+  for (int i = i0 + threadIdx.x; i < min(n, i0 + MT_CHUNK); i += 256) g[i] *= c;
+}
+
+// torch.optim.AdamW (decoupled weight decay, no amsgrad, not maximize):
+//   p *= 1 - lr wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;
+//   p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps),   bc_i = 1 - b_i^step
+__global__ void __launch_bounds__(256)
+k_adamw(MultiTensor t, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+        const float* __restrict__ sumsq, float max_norm) {
+  const int ti = blockIdx.y, n = t.numel[ti];
+  const int i0 = blockIdx.x * MT_CHUNK;
+  if (i0 >= n) return;
+  const float c = clip_coef(sumsq, max_norm);
+  float* __restrict__ p = t.p[ti];
+  const float* __restrict__ g = t.g[ti];
+  float* __restrict__ m = t.m[ti];
+  float* __restrict__ v = t.v[ti];
+  const float step_size = lr / bc1;
+  for (int i = i0 + threadIdx.x; i < min(n, i0 + MT_CHUNK); i += 256) {
+    const float gi = g[i] * c;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    pi -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    p[i] = pi;
+  }
+}
+
+static int fill_table(MultiTensor& t, int k0, int n, float* const* p, const float* const* g, float* const* m,
+                      float* const* v, const int* numel, int* max_numel) {
+  t.n = n - k0 < MT_MAX ? n - k0 : MT_MAX;
+  *max_numel = 0;
+  for (int j = 0; j < t.n; ++j) {
+    t.p[j] = p ? p[k0 + j] : nullptr;
+    t.g[j] = g ? g[k0 + j] : nullptr;
+    t.m[j] = m ? m[k0 + j] : nullptr;
+    t.v[j] = v ? v[k0 + j] : nullptr;
+    t.numel[j] = numel[k0 + j];
+    if (numel[k0 + j] > *max_numel) *max_numel = numel[k0 + j];
+  }
+  return t.n;
+}
+
 // *flag |= bit when any element is outside (-limit, limit) or is NaN (limit = +inf: a pure finiteness check)
 __global__ void k_range_flag(const float* __restrict__ x, long long n, float limit, int* __restrict__ flag, int bit) {
   bool bad = false;
@@ -157,6 +251,51 @@ __global__ void k_range_flag(const float* __restrict__ x, long long n, float lim
 }
 
 }  // namespace
+
+extern "C" int mpnn_grad_sumsq(int n, const float* const* grads, const int* numel, float* sumsq, void* stream) {
+  MPNN_CHECK_ARG(n > 0 && grads && numel && sumsq, "mpnn_grad_sumsq: bad arguments");
+  for (int j = 0; j < n; ++j) MPNN_CHECK_ARG(grads[j] && numel[j] > 0, "mpnn_grad_sumsq: null or empty tensor");
+  for (int k0 = 0; k0 < n; k0 += MT_MAX) {
+    MultiTensor t;
+    int mx;
+    fill_table(t, k0, n, nullptr, grads, nullptr, nullptr, numel, &mx);
+    hipLaunchKernelGGL(k_grad_sumsq, dim3((mx + MT_CHUNK - 1) / MT_CHUNK, t.n), dim3(256), 0, (hipStream_t)stream, t, sumsq);
+  }
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_grad_scale(int n, float* const* grads, const int* numel, const float* sumsq, float max_norm,
+                               void* stream) {
+  MPNN_CHECK_ARG(n > 0 && grads && numel && sumsq && max_norm > 0.f, "mpnn_grad_scale: bad arguments");
+  for (int j = 0; j < n; ++j) MPNN_CHECK_ARG(grads[j] && numel[j] > 0, "mpnn_grad_scale: null or empty tensor");
+  for (int k0 = 0; k0 < n; k0 += MT_MAX) {
+    MultiTensor t;
+    int mx;
+    fill_table(t, k0, n, grads, nullptr, nullptr, nullptr, numel, &mx);
+    hipLaunchKernelGGL(k_grad_scale, dim3((mx + MT_CHUNK - 1) / MT_CHUNK, t.n), dim3(256), 0, (hipStream_t)stream, t, sumsq,
+                       max_norm);
+  }
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_adamw_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,
+                               float* const* exp_avg_sq, const int* numel, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int step, const float* grad_sumsq, float max_norm, void* stream) {
+  MPNN_CHECK_ARG(n > 0 && params && grads && exp_avg && exp_avg_sq && numel && step >= 1, "mpnn_adamw_step: bad arguments");
+  MPNN_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f && lr >= 0.f,
+                 "mpnn_adamw_step: bad hyper-parameters");
+  for (int j = 0; j < n; ++j)
+    MPNN_CHECK_ARG(params[j] && grads[j] && exp_avg[j] && exp_avg_sq[j] && numel[j] > 0, "mpnn_adamw_step: null or empty tensor");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  for (int k0 = 0; k0 < n; k0 += MT_MAX) {
+    MultiTensor t;
+    int mx;
+    fill_table(t, k0, n, params, grads, exp_avg, exp_avg_sq, numel, &mx);
+    hipLaunchKernelGGL(k_adamw, dim3((mx + MT_CHUNK - 1) / MT_CHUNK, t.n), dim3(256), 0, (hipStream_t)stream, t, lr, beta1,
+                       beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_sumsq, max_norm);
+  }
+  MPNN_LAUNCH_CHECK();
+}
 
 extern "C" int mpnn_range_flag(const float* x, long long n, float limit, int32_t* flag, int bit, void* stream) {
   MPNN_CHECK_ARG(x && flag && n > 0 && bit != 0, "mpnn_range_flag: bad arguments");

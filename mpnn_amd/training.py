@@ -643,13 +643,17 @@ def loss_nll(S, log_probs, mask):
     return loss, torch.sum(loss * mask) / torch.sum(mask), true_false
 
 
-def make_optimizer(model, lr=1e-3, weight_decay=1e-2, total_steps=None):
+def make_optimizer(model, lr=1e-3, weight_decay=1e-2, total_steps=None, max_grad_norm=0.0):
     """AdamW and, when `total_steps` is given, the reference's schedule (train.py:217-222): linear warm-up from 1e-8 over
-    the first 1 % of the steps, then cosine annealing to 0.  The optimizer is torch's fused (multi-tensor) AdamW: one
-    launch for all 1.66 M parameters.  -> (optimizer, scheduler or None)."""
+    the first 1 % of the steps, then cosine annealing to 0.  On a ROCm device the optimizer is the in-tree multi-tensor
+    kernel (`mpnn_amd.optim.AdamW`: all 1.66 M parameters in three launches, gradient clipping of train.py:389-390
+    folded in when `max_grad_norm` > 0); a model on the CPU gets torch's.  -> (optimizer, scheduler or None)."""
     from torch.optim.lr_scheduler import CosineAnnealingLR, LinearLR, SequentialLR
-    fused = all(p.is_cuda for p in model.parameters())
-    optimizer = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay, fused=fused)
+    if all(p.is_cuda for p in model.parameters()):
+        from .optim import AdamW
+        optimizer = AdamW(model.parameters(), lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+    else:
+        optimizer = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
     if total_steps is None:
         return optimizer, None
     warmup_steps = int(0.01 * total_steps)
@@ -675,7 +679,11 @@ def train_step(model, optimizer, batch, world_size=1, fix_order=None, fix_backbo
     loss.backward()
     distributed.allreduce_gradients(model.parameters(), world_size)  # no-op for a single rank
     if max_grad_norm and max_grad_norm > 0.0:
-        torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
+        from . import optim
+        if isinstance(optimizer, optim.AdamW):
+            optimizer.max_grad_norm = float(max_grad_norm)      # clipped inside the update pass
+        else:
+            optim.clip_grad_norm_(list(model.parameters()), max_grad_norm)
     optimizer.step()
     if scheduler is not None:
         scheduler.step()

@@ -132,7 +132,7 @@ def test_optimizer_schedule_and_nll_match_the_reference_recipe():
 
     lin = torch.nn.Linear(4, 3)
     opt, sched = training.make_optimizer(lin, lr=2e-3, total_steps=1000)
-    assert isinstance(opt, torch.optim.AdamW) and opt.defaults["weight_decay"] == 1e-2
+    assert isinstance(opt, torch.optim.AdamW) and opt.defaults["weight_decay"] == 1e-2   # CPU module: torch's AdamW
     lrs = []
     for _ in range(1000):
         lrs.append(opt.param_groups[0]["lr"])
