@@ -629,6 +629,31 @@ def main():
               "note": "per rank; the CPU side of the same workload is cpu_baseline.c1_forward"}
         assert torch.isfinite(o).all()
     log("C1 leg done")
+    # ---- secondary: the edge-list model family on the same B x L proteins in the flat layout
+    sparse = None
+    if not a.no_f16_leg:
+        from mpnn_amd.sparse import ProteinMPNN as SparseMPNN
+        from mpnn_amd.synthetic import synthetic_flat_batch
+
+        torch.manual_seed(0)
+        sm = SparseMPNN(num_neighbors=K).eval().to(dev)
+        fb = synthetic_flat_batch([L] * B, seed=6000 + rank, device=dev)
+        so_ = fb.pop("decoding_order")
+        with torch.no_grad():
+            for _ in range(2):
+                o = sm(**fb, decoding_order=so_)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                o = sm(**fb, decoding_order=so_)
+            torch.cuda.synchronize()
+        assert torch.isfinite(o).all()
+        sparse = {"workload": f"mpnn_amd.sparse.ProteinMPNN (protein_mpnn.py), {B} graphs x {L} nodes, knn {K} with self "
+                              "loops, 3 enc + 3 dec, flat layout in / out (per rank)",
+                  "residues_per_s": round(B * L * 5 / (time.perf_counter() - t1), 1),
+                  "note": "same kernels as the dense path (mpnn_edge_features_biased, mpnn_dec_message_valid); includes "
+                          "the flat <-> padded scatter and one host read of the largest graph size"}
+    log("sparse leg done")
     train = None
     if a.train_batch > 0:
         train = train_leg(a, dev, rank, world, dist, barrier, _lib)
@@ -661,6 +686,7 @@ def main():
             "kernel_rooflines": kernel_rooflines,
             "shared_structure": shared,
             "c1_forward": c1,
+            "sparse_forward": sparse,
         }
         line["forward_f16_products"] = dict(f16, note="per-rank; one f16 MFMA product per fp32 product instead of three; "
                                             "fp32 accumulate / GELU / LayerNorm; tolerance in include/mpnn_hip.h")

@@ -94,6 +94,14 @@ int mpnn_edge_features(const float* atoms, const int32_t* E_idx32, const int64_t
                        const float* We_bias, int B, int L, int K, int n_atoms, float* E_natural, float* hE_frag,
                        void* stream);
 
+/* mpnn_edge_features with a bias on the embedding before its LayerNorm: the sparse variant's edge_mlp =
+ * Linear(with bias) -> LayerNorm -> Linear (src/mpnn/models/protein_mpnn.py:286-292, :484).  Wemb_bias [128]. */
+int mpnn_edge_features_biased(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
+                              const int64_t* chain_labels, const float* pos_table, const float* rbf_mu,
+                              const float* Wemb_packed, const float* Wemb_bias, const float* ln_w, const float* ln_b,
+                              const float* We_packed, const float* We_bias, int B, int L, int K, int n_atoms,
+                              float* E_natural, float* hE_frag, void* stream);
+
 /* layout converters for API surfaces that expose h_E as [n_nodes, K, 128] (EncLayer / features, :73, :360). */
 int mpnn_edges_to_natural(const float* hE_frag, int n_nodes, int K, float* natural, void* stream);
 int mpnn_edges_from_natural(const float* natural, int n_nodes, int K, float* hE_frag, void* stream);
@@ -137,6 +145,16 @@ int mpnn_dec_message_shared(const float* hE_frag, const float* PQ, int ldpq, int
                             int ldenc, int offEnc, const int32_t* rank, const int32_t* E_idx32, const float* mask,
                             const float* edge_mask, const float* W1b_packed, const float* W2_packed, const float* b2,
                             int B, int n_struct, int L, int K, float* gsum, void* stream);
+
+/* Decoder message of the sparse variant (src/mpnn/models/protein_mpnn.py Decoder.message, :203-217, summed over the
+ * edges of the target by MessagePassing's default "add"): every edge reads the neighbour's CURRENT projections - the
+ * A block (neighbour term + label term) where the neighbour is decoded earlier (rank_i > rank_j), else the B block
+ * (neighbour term only) - and only edges with edge_mask = 1 enter the neighbour sum (the dense kernels sum all K).
+ * PQ [B*L, ldpq] holds Pa | A | B at offPa / offA / offB; edge_mask [B,L,K] is required. */
+int mpnn_dec_message_valid(const float* hE_frag, const float* PQ, int ldpq, int offPa, int offA, int offB,
+                           const int32_t* rank, const int32_t* E_idx32, const float* mask, const float* edge_mask,
+                           const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K,
+                           float* gsum, void* stream);
 
 /* Node update shared by EncLayer / DecLayer (:81-88, :127-137, FFN :151-155) followed by the next kernels'
  * node projections:  dh = (W3 gsum + cnt b3) / scale;  x = LN1(h + dh);  h' = mask LN2(x + FFN(x));
@@ -393,6 +411,16 @@ int mpnn_edge_features_f16(const float* atoms, const int32_t* E_idx32, const int
                        const float* Wemb_packed, const float* ln_w, const float* ln_b, const float* We_packed,
                        const float* We_bias, int B, int L, int K, int n_atoms, float* E_natural, float* hE_frag,
                        void* stream);
+
+int mpnn_edge_features_biased_f16(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
+                                  const int64_t* chain_labels, const float* pos_table, const float* rbf_mu,
+                                  const float* Wemb_packed, const float* Wemb_bias, const float* ln_w,
+                                  const float* ln_b, const float* We_packed, const float* We_bias, int B, int L, int K,
+                                  int n_atoms, float* E_natural, float* hE_frag, void* stream);
+int mpnn_dec_message_valid_f16(const float* hE_frag, const float* PQ, int ldpq, int offPa, int offA, int offB,
+                               const int32_t* rank, const int32_t* E_idx32, const float* mask, const float* edge_mask,
+                               const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K,
+                               float* gsum, void* stream);
 
 int mpnn_enc_message_f16(const float* hE_frag, const float* PQ, int ldpq, int offP, int offQ, const int32_t* E_idx32,
                      const float* mask, const float* edge_mask, const float* W1b_packed, const float* W2_packed,

@@ -27,6 +27,7 @@ SIGNATURES = {
     "mpnn_knn_topk": [_P, _I, _I, _I, _F, _P, _P, _P, _P, _P],
     "mpnn_occupancy": [_P, _P, _I, _I, _F, _P, _P],
     "mpnn_edge_features": [_P] * 11 + [_I, _I, _I, _I, _P, _P, _P],
+    "mpnn_edge_features_biased": [_P] * 12 + [_I, _I, _I, _I, _P, _P, _P],
     "mpnn_edges_to_natural": [_P, _I, _I, _P, _P],
     "mpnn_edges_from_natural": [_P, _I, _I, _P, _P],
     "mpnn_order_rank": [_P, _I, _I, _P, _P],
@@ -34,6 +35,7 @@ SIGNATURES = {
     "mpnn_enc_message": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "mpnn_enc_edge_update": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "mpnn_dec_message": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
+    "mpnn_dec_message_valid": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "mpnn_dec_message_shared": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "mpnn_node_update": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _I,
                          _P, _I, _I, _P, _I, _I, _P, _P, _P],
@@ -79,7 +81,7 @@ SIGNATURES = {
 # reduced-precision twins (one f16 product per fp32 product) of the forward entry points: same signatures
 F16_ENTRIES = ("mpnn_edge_features", "mpnn_enc_message", "mpnn_enc_edge_update", "mpnn_dec_message", "mpnn_node_update",
                "mpnn_dec_message_subset", "mpnn_node_update_subset", "mpnn_dec_message_shared", "mpnn_dec_layer_subset",
-               "mpnn_linear_rows")
+               "mpnn_linear_rows", "mpnn_edge_features_biased", "mpnn_dec_message_valid")
 for _n in F16_ENTRIES:
     SIGNATURES[_n + "_f16"] = SIGNATURES[_n]
 

@@ -182,7 +182,7 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
           const int* __restrict__ rank, const int* __restrict__ E_idx, const float* __restrict__ mask,
           const float* __restrict__ edge_mask, const h8* __restrict__ W1b, const h8* __restrict__ W2,
           const float* __restrict__ b2, int N, int L, int K, float* __restrict__ gsum, float* __restrict__ cnt,
-          f32x4* __restrict__ sv1, f32x4* __restrict__ sv2, int enc_mod) {
+          f32x4* __restrict__ sv1, f32x4* __restrict__ sv2, int enc_mod, int w_valid) {
   __shared__ h8 lds[2 * WSPLIT];
   __shared__ __align__(16) float b2s[MPNN_H];  // bias from LDS: a global load would queue behind the row gathers
   lds_fill(lds, W1b, WSPLIT);
@@ -222,7 +222,7 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
         const int je = (sh / L) * L + jl;
         row[c] = before ? (Abuf + (size_t)jn * lda + offA + 4 * g) : (Bbuf + (size_t)je * ldb + offB + 4 * g);
         s[c] = mi * em;
-        w[c] = e < K ? 1.0f : 0.0f;
+        w[c] = e < K ? (w_valid ? em : 1.0f) : 0.0f;  // w_valid: sum over valid edges only (sparse variant)
       } else {
         row[c] = Abuf + (size_t)jn * lda + offA + 4 * g;
         s[c] = 1.0f;
@@ -563,7 +563,7 @@ k_message_tiles(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, in
                 const int* __restrict__ rank, const int* __restrict__ E_idx, const float* __restrict__ mask,
                 const float* __restrict__ edge_mask, const h8* __restrict__ W1b, const h8* __restrict__ W2,
                 const float* __restrict__ b2, int N, int L, int K, int KT, float* __restrict__ gsum,
-                float* __restrict__ cnt) {
+                float* __restrict__ cnt, int w_valid) {
   __shared__ h8 lds[2 * WSPLIT];
   lds_fill(lds, W1b, WSPLIT);
   lds_fill(lds + WSPLIT, W2, WSPLIT);
@@ -598,7 +598,7 @@ k_message_tiles(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, in
         const bool before = ri > rank[jn];
         row = before ? (Abuf + (size_t)jn * lda + offA + 4 * g) : (Bbuf + (size_t)jn * ldb + offB + 4 * g);
         sc = mi * em;
-        w = e < K ? 1.0f : 0.0f;
+        w = e < K ? (w_valid ? em : 1.0f) : 0.0f;
       } else {
         row = Abuf + (size_t)jn * lda + offA + 4 * g;
         sc = 1.0f;
@@ -913,14 +913,14 @@ extern "C" int MPNN_API(mpnn_enc_message)(const float* hE_frag, const float* PQ,
     dim3 grid(edge_grid(N, MPNN_MSGT_WAVES)), block(MPNN_MSGT_WAVES * 64);
     hipLaunchKernelGGL((k_message_tiles<false>), grid, block, 0, (hipStream_t)stream, (const f32x4*)hE_frag, PQ, ldpq,
                        offP, PQ, ldpq, offQ, (const float*)nullptr, 0, 0, (const int*)nullptr, E_idx32, mask,
-                       edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2, N, L, K, KT, gsum, cnt);
+                       edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2, N, L, K, KT, gsum, cnt, 0);
     MPNN_LAUNCH_CHECK();
   }
   dim3 grid(edge_grid(N, MPNN_MSG_WAVES)), block(MPNN_MSG_WAVES * 64);
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, false, false>), grid, block, 0, (hipStream_t)stream,
                                      (const f32x4*)hE_frag, PQ, ldpq, offP, PQ, ldpq, offQ, (const float*)nullptr, 0, 0,
                                      (const int*)nullptr, E_idx32, mask, edge_mask, (const h8*)W1b_packed,
-                                     (const h8*)W2_packed, b2, N, L, K, gsum, cnt, (f32x4*)nullptr, (f32x4*)nullptr, N));
+                                     (const h8*)W2_packed, b2, N, L, K, gsum, cnt, (f32x4*)nullptr, (f32x4*)nullptr, N, 0));
   MPNN_LAUNCH_CHECK();
 }
 
@@ -948,7 +948,7 @@ static int launch_dec_message(const char* who, const float* hE_frag, const float
                               const float* PVenc, int ldenc, int offEnc, const int32_t* rank, const int32_t* E_idx32,
                               const float* mask, const float* edge_mask, const float* W1b_packed,
                               const float* W2_packed, const float* b2, int B, int n_struct, int L, int K, float* gsum,
-                              void* stream) {
+                              void* stream, int w_valid = 0) {
   MPNN_CHECK_ARG(hE_frag && PQ && PVenc && rank && E_idx32 && mask && W1b_packed && W2_packed && b2 && gsum,
                  "mpnn_dec_message: null pointer");
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && mult4(ldpq, offPa, offA, ldenc, offEnc),
@@ -961,14 +961,15 @@ static int launch_dec_message(const char* who, const float* hE_frag, const float
     dim3 grid(edge_grid(N, MPNN_MSGT_WAVES)), block(MPNN_MSGT_WAVES * 64);
     hipLaunchKernelGGL((k_message_tiles<true>), grid, block, 0, (hipStream_t)stream, (const f32x4*)hE_frag, PQ, ldpq,
                        offPa, PQ, ldpq, offA, PVenc, ldenc, offEnc, rank, E_idx32, mask, edge_mask,
-                       (const h8*)W1b_packed, (const h8*)W2_packed, b2, N, L, K, KT, gsum, (float*)nullptr);
+                       (const h8*)W1b_packed, (const h8*)W2_packed, b2, N, L, K, KT, gsum, (float*)nullptr, w_valid);
     MPNN_LAUNCH_CHECK();
   }
   dim3 grid(edge_grid(N, MPNN_MSG_WAVES)), block(MPNN_MSG_WAVES * 64);
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, true, false>), grid, block, 0, (hipStream_t)stream,
                                      (const f32x4*)hE_frag, PQ, ldpq, offPa, PQ, ldpq, offA, PVenc, ldenc, offEnc, rank,
                                      E_idx32, mask, edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2,
-                                     N, L, K, gsum, (float*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr, n_struct * L));
+                                     N, L, K, gsum, (float*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr, n_struct * L,
+                                     w_valid));
   MPNN_LAUNCH_CHECK();
 }
 
@@ -979,6 +980,18 @@ extern "C" int MPNN_API(mpnn_dec_message)(const float* hE_frag, const float* PQ,
                                 float* gsum, void* stream) {
   return launch_dec_message("mpnn_dec_message", hE_frag, PQ, ldpq, offPa, offA, PVenc, ldenc, offEnc, rank, E_idx32, mask,
                             edge_mask, W1b_packed, W2_packed, b2, B, B, L, K, gsum, stream);
+}
+
+// the sparse variant's decoder (protein_mpnn.py:203-217): every edge of the list reads the neighbour's CURRENT row
+// (A with the label term where the neighbour is decoded earlier, else B without it) and only the VALID edges
+// (edge_mask = 1) enter the neighbour sum; PQ holds [Pa | A | B] per residue
+extern "C" int MPNN_API(mpnn_dec_message_valid)(const float* hE_frag, const float* PQ, int ldpq, int offPa, int offA,
+                                      int offB, const int32_t* rank, const int32_t* E_idx32, const float* mask,
+                                      const float* edge_mask, const float* W1b_packed, const float* W2_packed,
+                                      const float* b2, int B, int L, int K, float* gsum, void* stream) {
+  MPNN_CHECK_ARG(edge_mask, "mpnn_dec_message_valid: the edge validity mask is required");
+  return launch_dec_message("mpnn_dec_message_valid", hE_frag, PQ, ldpq, offPa, offA, PQ, ldpq, offB, rank, E_idx32, mask,
+                            edge_mask, W1b_packed, W2_packed, b2, B, B, L, K, gsum, stream, 1);
 }
 
 // B rows (sequences / decoding orders) on n_struct structures: row r decodes structure r % n_struct
@@ -1008,12 +1021,12 @@ extern "C" int mpnn_message_train(int dec, const float* hE_frag, const float* P,
     KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, true, true>), grid, block, 0, (hipStream_t)stream,
                                        (const f32x4*)hE_frag, P, 128, 0, RowA, 128, 0, RowB, 128, 0, rank, E_idx32,
                                        mask, edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2, N, L, K, gsum,
-                                       (float*)nullptr, (f32x4*)a1_frag, (f32x4*)a2_frag, N));
+                                       (float*)nullptr, (f32x4*)a1_frag, (f32x4*)a2_frag, N, 0));
   } else {
     KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, false, true>), grid, block, 0, (hipStream_t)stream,
                                        (const f32x4*)hE_frag, P, 128, 0, RowA, 128, 0, (const float*)nullptr, 0, 0,
                                        (const int*)nullptr, E_idx32, mask, edge_mask, (const h8*)W1b_packed,
-                                       (const h8*)W2_packed, b2, N, L, K, gsum, cnt, (f32x4*)a1_frag, (f32x4*)a2_frag, N));
+                                       (const h8*)W2_packed, b2, N, L, K, gsum, cnt, (f32x4*)a1_frag, (f32x4*)a2_frag, N, 0));
   }
   MPNN_LAUNCH_CHECK();
 }

@@ -297,7 +297,7 @@ k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, 
                 const float* __restrict__ rbf_mu, const h8* __restrict__ Wemb, const float* __restrict__ ln_w,
                 const float* __restrict__ ln_b, const h8* __restrict__ We, const float* __restrict__ be, int N,
                 int L, int K, float* __restrict__ E_nat, float* __restrict__ hE, f32x4* __restrict__ E0_frag,
-                f32x4* __restrict__ E_frag) {
+                f32x4* __restrict__ E_frag, const float* __restrict__ emb_bias) {
   constexpr int NT_IN = A * A + 1;            // feature tiles: pairs, then positional
   constexpr int NKK_IN = (NT_IN + 1) / 2;     // k-steps of 32 features
   constexpr int D = MPNN_FEAT_RING;
@@ -312,11 +312,15 @@ k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, 
 #pragma unroll
   for (int c = 0; c < KT; ++c) jn[c] = b * L + E_idx[(size_t)node * Kp + 16 * c + col];
 
+  // the embedding's bias (the sparse variant's edge_mlp.0 has one, protein_mpnn.py:286-292; the dense one has none)
   f32x4 acc[MPNN_NT][KT];
 #pragma unroll
-  for (int t = 0; t < MPNN_NT; ++t)
+  for (int t = 0; t < MPNN_NT; ++t) {
+    f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (emb_bias) b0 = *reinterpret_cast<const f32x4*>(emb_bias + 16 * t + 4 * (lane >> 4));
 #pragma unroll
-    for (int c = 0; c < KT; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < KT; ++c) acc[t][c] = b0;
+  }
 
   float mu[4];
 #pragma unroll
@@ -593,12 +597,12 @@ static int launch_edge_features(int A, const float* atoms, const int* E_idx, con
                                 const long long* chain, const float* pos_table, const float* rbf_mu,
                                 const float* Wemb, const float* ln_w, const float* ln_b, const float* We,
                                 const float* be, int N, int L, int K, float* E_nat, float* hE, hipStream_t s,
-                                float* E0_frag = nullptr, float* E_frag = nullptr) {
+                                float* E0_frag = nullptr, float* E_frag = nullptr, const float* emb_bias = nullptr) {
   dim3 grid(ceil_div(N, 4)), block(256);
 #define MPNN_FEAT_LAUNCH(AA, SV)                                                                                  \
   hipLaunchKernelGGL((k_edge_features<KT, AA, SV>), grid, block, 0, s, atoms, E_idx, ridx, chain, pos_table, rbf_mu, \
                      (const h8*)Wemb, ln_w, ln_b, (const h8*)We, be, N, L, K, E_nat, hE, (f32x4*)E0_frag,          \
-                     (f32x4*)E_frag)
+                     (f32x4*)E_frag, emb_bias)
   const bool save = E0_frag != nullptr;
   if (A == 5) {
     if (save) MPNN_FEAT_LAUNCH(5, true); else MPNN_FEAT_LAUNCH(5, false);
@@ -609,11 +613,11 @@ static int launch_edge_features(int A, const float* atoms, const int* E_idx, con
   MPNN_LAUNCH_CHECK();
 }
 
-extern "C" int MPNN_API(mpnn_edge_features)(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
-                                  const int64_t* chain_labels, const float* pos_table, const float* rbf_mu,
-                                  const float* Wemb_packed, const float* ln_w, const float* ln_b,
-                                  const float* We_packed, const float* We_bias, int B, int L, int K, int n_atoms,
-                                  float* E_natural, float* hE_frag, void* stream) {
+static int edge_features_entry(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
+                               const int64_t* chain_labels, const float* pos_table, const float* rbf_mu,
+                               const float* Wemb_packed, const float* Wemb_bias, const float* ln_w, const float* ln_b,
+                               const float* We_packed, const float* We_bias, int B, int L, int K, int n_atoms,
+                               float* E_natural, float* hE_frag, void* stream) {
   MPNN_CHECK_ARG(atoms && E_idx32 && residue_idx && chain_labels && pos_table && rbf_mu && Wemb_packed && ln_w &&
                      ln_b && We_packed && We_bias && hE_frag,
                  "mpnn_edge_features: null pointer");
@@ -622,12 +626,37 @@ extern "C" int MPNN_API(mpnn_edge_features)(const float* atoms, const int32_t* E
   const int KT = (K + 15) / 16, N = B * L;
   hipStream_t s = (hipStream_t)stream;
   const long long *ri = (const long long*)residue_idx, *cl = (const long long*)chain_labels;
+#define MPNN_FEAT_CASE(kt)                                                                                          \
+  return launch_edge_features<kt>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b,      \
+                                  We_packed, We_bias, N, L, K, E_natural, hE_frag, s, nullptr, nullptr, Wemb_bias)
   switch (KT) {
-    case 1: return launch_edge_features<1>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, E_natural, hE_frag, s);
-    case 2: return launch_edge_features<2>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, E_natural, hE_frag, s);
-    case 3: return launch_edge_features<3>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, E_natural, hE_frag, s);
-    default: return launch_edge_features<4>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, E_natural, hE_frag, s);
+    case 1: MPNN_FEAT_CASE(1);
+    case 2: MPNN_FEAT_CASE(2);
+    case 3: MPNN_FEAT_CASE(3);
+    default: MPNN_FEAT_CASE(4);
   }
+#undef MPNN_FEAT_CASE
+}
+
+extern "C" int MPNN_API(mpnn_edge_features)(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
+                                  const int64_t* chain_labels, const float* pos_table, const float* rbf_mu,
+                                  const float* Wemb_packed, const float* ln_w, const float* ln_b,
+                                  const float* We_packed, const float* We_bias, int B, int L, int K, int n_atoms,
+                                  float* E_natural, float* hE_frag, void* stream) {
+  return edge_features_entry(atoms, E_idx32, residue_idx, chain_labels, pos_table, rbf_mu, Wemb_packed, nullptr, ln_w,
+                             ln_b, We_packed, We_bias, B, L, K, n_atoms, E_natural, hE_frag, stream);
+}
+
+// the same kernel with a bias on the embedding before its LayerNorm (the sparse variant's edge_mlp.0)
+extern "C" int MPNN_API(mpnn_edge_features_biased)(const float* atoms, const int32_t* E_idx32,
+                                         const int64_t* residue_idx, const int64_t* chain_labels,
+                                         const float* pos_table, const float* rbf_mu, const float* Wemb_packed,
+                                         const float* Wemb_bias, const float* ln_w, const float* ln_b,
+                                         const float* We_packed, const float* We_bias, int B, int L, int K,
+                                         int n_atoms, float* E_natural, float* hE_frag, void* stream) {
+  MPNN_CHECK_ARG(Wemb_bias, "mpnn_edge_features_biased: null bias");
+  return edge_features_entry(atoms, E_idx32, residue_idx, chain_labels, pos_table, rbf_mu, Wemb_packed, Wemb_bias, ln_w,
+                             ln_b, We_packed, We_bias, B, L, K, n_atoms, E_natural, hE_frag, stream);
 }
 
 #ifndef MPNN_FAST

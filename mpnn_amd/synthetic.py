@@ -200,3 +200,23 @@ def synthetic_entries(n: int, seed: int = 0, min_len: int = 40, max_len: int = 4
         entry["seq"] = "".join(seqs)
         entries.append(entry)
     return entries
+
+
+def synthetic_flat_batch(lengths: list[int], seed: int = 0, n_chains: int = 1, design_fraction: float = 1.0,
+                         unresolved_every: int = 0, device: str | torch.device = "cpu") -> dict[str, torch.Tensor]:
+    """The same synthetic proteins in the flat layout of the sparse model (mpnn_amd.sparse.ProteinMPNN; reference
+    src/mpnn/models/protein_mpnn.py:450-459): x [n,4,3], chain_seq_label, mask, chain_mask_all, residue_idx,
+    chain_encoding_all, batch [n], plus decoding_order [B, max(lengths)] over the padded rows.
+    unresolved_every = m > 0 marks every m-th residue unresolved (mask 0, coordinates NaN: nothing may read them)."""
+    B, L = len(lengths), max(lengths)
+    d = synthetic_batch(B, L, seed=seed, lengths=lengths, n_chains=n_chains, design_fraction=design_fraction)
+    keep = d["mask"] > 0
+    batch = torch.arange(B)[:, None].expand(B, L)[keep]
+    out = dict(x=d["X"][keep], chain_seq_label=d["S"][keep], mask=d["mask"][keep], chain_mask_all=d["chain_M"][keep],
+               residue_idx=d["residue_idx"][keep], chain_encoding_all=d["chain_encoding_all"][keep], batch=batch,
+               decoding_order=d["fix_order"])
+    if unresolved_every > 0:
+        gone = (torch.arange(batch.numel()) % unresolved_every) == unresolved_every - 1
+        out["mask"] = torch.where(gone, torch.zeros(()), out["mask"])
+        out["x"] = torch.where(gone[:, None, None], torch.full((), float("nan")), out["x"])
+    return {k: v.to(device) for k, v in out.items()}
