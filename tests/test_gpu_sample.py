@@ -114,7 +114,12 @@ def test_low_temperature_is_argmax_and_seed_reproducible():
     args = (b["X"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
     a = model.sample(*args, n_samples=2, temperature=1e-4, seed=5)
     designed = ((b["chain_M"] * b["mask"]) > 0).unsqueeze(0).expand_as(a["S"])
-    assert torch.equal(a["S"][designed], a["log_probs"].argmax(-1)[designed])
+    # where the two best letters are further apart than 100 temperatures the draw IS the argmax (a closer runner-up
+    # keeps a real share of the distribution: exp(-gap / T))
+    top2 = a["log_probs"].topk(2, dim=-1).values
+    clear = designed & ((top2[..., 0] - top2[..., 1]) > 1e-2)
+    assert float(clear.sum()) > 0.8 * float(designed.sum())
+    assert torch.equal(a["S"][clear], a["log_probs"].argmax(-1)[clear])
     a2 = model.sample(*args, n_samples=2, temperature=1e-4, seed=5)
     assert torch.equal(a["S"], a2["S"]) and torch.equal(a["order"], a2["order"])
     c = model.sample(*args, n_samples=2, temperature=1.0, seed=6)
