@@ -13,7 +13,7 @@ all: $(OUT)
 $(CSRC)/mpnn_featurizer.o: $(CSRC)/mpnn_featurizer.hip $(CSRC)/mpnn_common.h
 	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $< -o $@
 
-$(CSRC)/mpnn_edge.o: $(CSRC)/mpnn_edge.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h
+$(CSRC)/mpnn_edge.o: $(CSRC)/mpnn_edge.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h $(CSRC)/mpnn_sample.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/mpnn_edge_bwd.o: $(CSRC)/mpnn_edge_bwd.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h $(CSRC)/mpnn_bwd_common.h
@@ -36,7 +36,7 @@ clean:
 
 .PHONY: all clean
 
-$(CSRC)/mpnn_node.o: $(CSRC)/mpnn_node.hip $(CSRC)/mpnn_common.h
+$(CSRC)/mpnn_node.o: $(CSRC)/mpnn_node.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_sample.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/mpnn_node_bwd.o: $(CSRC)/mpnn_node_bwd.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h $(CSRC)/mpnn_bwd_common.h
@@ -46,7 +46,7 @@ $(CSRC)/mpnn_node_bwd.o: $(CSRC)/mpnn_node_bwd.hip $(CSRC)/mpnn_common.h $(CSRC)
 $(CSRC)/mpnn_featurizer_f16.o: $(CSRC)/mpnn_featurizer.hip $(CSRC)/mpnn_common.h
 	$(HIPCC) $(HIPFLAGS) -DMPNN_FAST -ffp-contract=off -c $< -o $@
 
-$(CSRC)/mpnn_edge_f16.o: $(CSRC)/mpnn_edge.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h
+$(CSRC)/mpnn_edge_f16.o: $(CSRC)/mpnn_edge.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h $(CSRC)/mpnn_sample.h
 	$(HIPCC) $(HIPFLAGS) -DMPNN_FAST -c $< -o $@
 
 $(CSRC)/mpnn_node_f16.o: $(CSRC)/mpnn_node.hip $(CSRC)/mpnn_common.h

@@ -156,6 +156,44 @@ int mpnn_dec_message_valid(const float* hE_frag, const float* PQ, int ldpq, int 
                            const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K,
                            float* gsum, void* stream);
 
+/* One dependency level of the autoregressive sampler in ONE launch: every listed residue goes through all decoder
+ * layers (mpnn_dec_layer_subset's arithmetic, layer after layer inside the workgroup that owns the residue) and the
+ * sampling head (mpnn_sample_subset's arithmetic: log-probs, tempered draw, sequence term folded into every layer's A
+ * rows).  Valid because a residue of a level reads only residues of earlier levels and its own rows.  No reference
+ * counterpart (the reference has no sampler).  layers[l] describes decoder layer l:
+ *   P / RowA (ld, off): the layer's Pa | A rows, per sample row; offEnc: column of its encoder rows in PVenc;
+ *   hV_in -> hV_out; PQ [.., nproj * 128]: the NEXT layer's Pa | A rows (nproj = 0 for the last layer);
+ *   layers[l].hV_in must be layers[l-1].hV_out and layers[l].P / RowA must live in layers[l-1].PQ.
+ * K <= 48, 1..4 layers, n_letters <= 32. */
+typedef struct mpnn_level_layer {
+  const float* P; int ldp, offP;
+  float* RowA; int lda, offA;      /* written too: the drawn letter's term is folded into the A rows */
+  int offEnc;
+  const float *W1b_packed, *W2_packed, *b2;
+  const float* hV_in;
+  const float *W3_packed, *b3, *ln1_w, *ln1_b, *Win_packed, *b_in, *Wout8_packed, *b_out, *ln2_w, *ln2_b;
+  float scale;
+  const float *Wproj_packed, *bproj; int nproj;
+  float* hV_out; float* PQ;
+} mpnn_level_layer;
+/* Validates the layer table and uploads its device form to plan_dev (MPNN_DECODE_PLAN_BYTES of device memory owned by
+ * the caller; stream-ordered copy): once per sampling call, before the first mpnn_decode_level that uses it. */
+#define MPNN_DECODE_PLAN_BYTES 1024
+int mpnn_decode_plan(const mpnn_level_layer* layers, int n_layers, void* plan_dev, void* stream);
+int mpnn_decode_plan_f16(const mpnn_level_layer* layers, int n_layers, void* plan_dev, void* stream);
+int mpnn_decode_level(const float* hE_frag, const float* PVenc, int ldenc, const int32_t* rank, const int32_t* E_idx32,
+                      const float* mask, const float* edge_mask, const int32_t* node_list, int n_list, int enc_nodes,
+                      int L, int K, float cnt_const, const void* plan_dev, int n_layers, const float* Wlogit_packed,
+                      const float* logit_b, const float* logit_bias, int n_letters, float temperature, uint64_t seed,
+                      const float* designable, const int64_t* S_in, int64_t* S_out, float* log_probs, const float* TS,
+                      int ld_ts, void* stream);
+int mpnn_decode_level_f16(const float* hE_frag, const float* PVenc, int ldenc, const int32_t* rank,
+                          const int32_t* E_idx32, const float* mask, const float* edge_mask, const int32_t* node_list,
+                          int n_list, int enc_nodes, int L, int K, float cnt_const, const void* plan_dev, int n_layers,
+                          const float* Wlogit_packed, const float* logit_b, const float* logit_bias, int n_letters,
+                          float temperature, uint64_t seed, const float* designable, const int64_t* S_in,
+                          int64_t* S_out, float* log_probs, const float* TS, int ld_ts, void* stream);
+
 /* Node update shared by EncLayer / DecLayer (:81-88, :127-137, FFN :151-155) followed by the next kernels'
  * node projections:  dh = (W3 gsum + cnt b3) / scale;  x = LN1(h + dh);  h' = mask LN2(x + FFN(x));
  *   PQ[n, 128 p : 128 (p+1)] = Wproj_p h' + bproj_p,  p < nproj;

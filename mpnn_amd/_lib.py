@@ -18,6 +18,18 @@ _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
 
+_U64 = ctypes.c_uint64
+
+
+class LevelLayer(ctypes.Structure):
+    """mpnn_level_layer (include/mpnn_hip.h): one decoder layer of mpnn_decode_level."""
+    _fields_ = [("P", _P), ("ldp", _I), ("offP", _I), ("RowA", _P), ("lda", _I), ("offA", _I), ("offEnc", _I),
+                ("W1b_packed", _P), ("W2_packed", _P), ("b2", _P), ("hV_in", _P),
+                ("W3_packed", _P), ("b3", _P), ("ln1_w", _P), ("ln1_b", _P), ("Win_packed", _P), ("b_in", _P),
+                ("Wout8_packed", _P), ("b_out", _P), ("ln2_w", _P), ("ln2_b", _P), ("scale", _F),
+                ("Wproj_packed", _P), ("bproj", _P), ("nproj", _I), ("hV_out", _P), ("PQ", _P)]
+
+
 # name -> argtypes (all return int except where noted)
 SIGNATURES = {
     "mpnn_pack_linear": [_P, _I, _I, _I, _I, _P, _P],
@@ -37,6 +49,9 @@ SIGNATURES = {
     "mpnn_dec_message": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "mpnn_dec_message_valid": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "mpnn_dec_message_shared": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "mpnn_decode_plan": [ctypes.POINTER(LevelLayer), _I, _P, _P],
+    "mpnn_decode_level": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P,
+                          _I, _F, _U64, _P, _P, _P, _P, _P, _I, _P],
     "mpnn_node_update": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _I,
                          _P, _I, _I, _P, _I, _I, _P, _P, _P],
     "mpnn_occupancy_mlp": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
@@ -81,7 +96,8 @@ SIGNATURES = {
 # reduced-precision twins (one f16 product per fp32 product) of the forward entry points: same signatures
 F16_ENTRIES = ("mpnn_edge_features", "mpnn_enc_message", "mpnn_enc_edge_update", "mpnn_dec_message", "mpnn_node_update",
                "mpnn_dec_message_subset", "mpnn_node_update_subset", "mpnn_dec_message_shared", "mpnn_dec_layer_subset",
-               "mpnn_linear_rows", "mpnn_edge_features_biased", "mpnn_dec_message_valid")
+               "mpnn_linear_rows", "mpnn_edge_features_biased", "mpnn_dec_message_valid",
+               "mpnn_decode_level", "mpnn_decode_plan")
 for _n in F16_ENTRIES:
     SIGNATURES[_n + "_f16"] = SIGNATURES[_n]
 

@@ -21,6 +21,7 @@
 //   * the edge update streams its third weight matrix from L2 three fragments ahead.
 // Two waves per SIMD (8-wave workgroups) let one wave's GELU / reductions run under the other's MFMAs.
 #include "mpnn_edge_common.h"
+#include "mpnn_hip.h"
 #include <stdio.h>
 
 // MPNN_STAMP: diagnostic build only (never shipped): per-phase shader-clock totals of the persistent edge kernels,
@@ -38,7 +39,7 @@ static void stamp_report(const char* what, int base) {
   if (!tot) return;
   fprintf(stderr, "[stamp %s]", what);
   for (int i = 0; i < 8; ++i) fprintf(stderr, " p%d=%.1f%%", i, 100.0 * h[base + i] / tot);
-  fprintf(stderr, "  total %.3e wave-cycles\n", (double)tot);
+  fprintf(stderr, "  total %.3e wave-cycles raw7 %llu\n", (double)tot, h[base + 7]);
   unsigned long long z[8] = {0};
   hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z), base * sizeof(unsigned long long));
 }
@@ -739,89 +740,130 @@ k_message_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, in
 #endif
 // residues per workgroup: 4 x 3 column tiles = one message item per wave (items of one wave run one after the other,
 // each with its own chain of dependent loads, so more residues per workgroup only lengthen the launch)
-constexpr int LV_NODES = 4;
-__global__ void __launch_bounds__(MPNN_MSGT_WAVES * 64)
-k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp, int offP,
-                  const float* __restrict__ Abuf, int lda, int offA, const float* __restrict__ Bbuf, int ldb, int offB,
-                  const int* __restrict__ rank, const int* __restrict__ E_idx, const float* __restrict__ mask,
-                  const float* __restrict__ edge_mask, const h8* __restrict__ W1b, const h8* __restrict__ W2,
-                  const float* __restrict__ b2, const int* __restrict__ node_list, int n_list, int enc_mod, int L, int K,
-                  int KT, const float* __restrict__ hV_in, float cnt_const, const h8* __restrict__ W3,
-                  const float* __restrict__ b3, const float* __restrict__ ln1w, const float* __restrict__ ln1b,
-                  const h8* __restrict__ Win, const float* __restrict__ bin, const h8* __restrict__ Wout,
-                  const float* __restrict__ bout, const float* __restrict__ ln2w, const float* __restrict__ ln2b,
-                  float inv_scale, const h8* __restrict__ Wproj, const float* __restrict__ bproj, int nproj,
-                  float* __restrict__ hV_out, float* __restrict__ PQ) {
-  __shared__ h8 lds[2 * WSPLIT];
-  __shared__ float gsl[16][MPNN_H];
-  const h8* W1s = lds;
-  const h8* W2s = lds + WSPLIT;
+constexpr int LV_NODES = 4;  // at most; small levels use fewer per workgroup (level_nodes_per_wg) to spread over more CUs
+// ---- pieces of a level kernel.  A workgroup of MPNN_MSGT_WAVES = 12 waves owns LV_NODES = 4 listed residues; with
+// K <= 48 (at most 3 column tiles) that is at most ONE message item (local residue, column tile) per wave.
+
+// what a wave knows about its message item before any layer runs: indices, scale / weight, where its hE tile is
+struct LevelItem {
+  bool has, before;
+  int nl, node;
+  float sc, w;
+  size_t rowA, rowB;  // row numbers of the gathered neighbour row in the A buffer / in the encoder rows
+  const f32x4* x;     // this lane's slice of the item's hE tile (feature tile t at x[t * xs])
+  int xs;
+};
+
+__device__ __forceinline__ void
+level_item_setup(LevelItem& it, const f32x4* __restrict__ hE, const int* __restrict__ rank, const int* __restrict__ E_idx,
+                 const float* __restrict__ mask, const float* __restrict__ edge_mask, const int* __restrict__ node_list,
+                 int tile, int lvn, int nlive, int enc_mod, int L, int K, int KT) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane >> 4, col = lane & 15;
+  const int col = lane & 15;
   const int Kp = KT * 16;
-  const int tile = blockIdx.x;
-  const int nlive = min(LV_NODES, n_list - tile * LV_NODES);
-  lds_fill(lds, W1b, WSPLIT);
-  lds_fill(lds + WSPLIT, W2, WSPLIT);
-  for (int i = threadIdx.x; i < 16 * MPNN_H; i += blockDim.x) (&gsl[0][0])[i] = 0.f;
-  __syncthreads();
-  // ---- message phase: item = (local residue, column tile)
-  for (int item = wave; item < nlive * KT; item += MPNN_MSGT_WAVES) {
-    LAUNDER(b2);
-    const int nl = item / KT, c = item % KT;
-    const int node = node_list[tile * LV_NODES + nl];
-    const int sh = node % enc_mod, b = node / L;
-    const int e = 16 * c + col;
-    const int jl = E_idx[(size_t)sh * Kp + e];
-    const int jn = b * L + jl;
-    float em = 1.0f;
-    if (edge_mask && e < K) em = edge_mask[(size_t)sh * K + e];
-    const bool before = rank[node] > rank[jn];
-    const float* row = before ? (Abuf + (size_t)jn * lda + offA + 4 * g)
-                              : (Bbuf + (size_t)((sh / L) * L + jl) * ldb + offB + 4 * g);
-    const float sc = mask[node] * em;
-    const float w = e < K ? 1.0f : 0.0f;
-    const float* Pi = Pbuf + (size_t)node * ldp + offP + 4 * g;
-    const f32x4* x = hE + ((size_t)sh * MPNN_NT * KT + c) * 64 + lane;
-    f32x4 xt[MPNN_NT], h1[MPNN_NT][1];
+  it.has = wave < nlive * KT;
+  const int item = it.has ? wave : 0;
+  const int c = item % KT;
+  it.nl = item / KT;
+  it.node = node_list[tile * lvn + it.nl];
+  const int sh = it.node % enc_mod, b = it.node / L;
+  const int e = 16 * c + col;
+  const int jl = E_idx[(size_t)sh * Kp + e];
+  const int jn = b * L + jl;
+  float em = 1.0f;
+  if (edge_mask && e < K) em = edge_mask[(size_t)sh * K + e];
+  it.before = rank[it.node] > rank[jn];
+  it.rowA = (size_t)jn;
+  it.rowB = (size_t)((sh / L) * L + jl);
+  it.sc = mask[it.node] * em;
+  it.w = e < K ? 1.0f : 0.0f;
+  it.x = hE + ((size_t)sh * MPNN_NT * KT + c) * 64 + lane;
+  it.xs = KT * 64;
+}
+
+// the item's hE tile and its gathered neighbour row for one layer (issued early: both depend on earlier levels only)
+__device__ __forceinline__ void
+level_rows_load(const LevelItem& it, const float* Abuf, int lda, int offA, const float* __restrict__ Bbuf, int ldb,
+                int offB, f32x4 (&xt)[MPNN_NT], f32x4 (&h1)[MPNN_NT][1]) {
+  const int g = (threadIdx.x & 63) >> 4;
+  const float* row = it.before ? (Abuf + it.rowA * lda + offA + 4 * g) : (Bbuf + it.rowB * ldb + offB + 4 * g);
 #pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t) {
-      xt[t] = x[(size_t)t * KT * 64];
-      h1[t][0] = row_tile(row, t);
-    }
+  for (int t = 0; t < MPNN_NT; ++t) {
+    xt[t] = it.x[(size_t)t * it.xs];
+    h1[t][0] = row_tile(row, t);
+  }
+}
+
+// message MLP of the item (weights in LDS), neighbour sum into gsl[nl] by LDS atomics
+__device__ __forceinline__ void
+level_message(const LevelItem& it, const h8* W1s, const h8* W2s, const float* __restrict__ b2, const float* Pbuf,
+              int ldp, int offP, const f32x4 (&xt)[MPNN_NT], f32x4 (&h1)[MPNN_NT][1], float (*gsl)[MPNN_H]) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, col = lane & 15;
+  LAUNDER(b2);
+  const float* Pi = Pbuf + (size_t)it.node * ldp + offP + 4 * g;
+  f32x4 p[MPNN_NT];
 #pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) {
-      BFrag bf[1];
-      split_pair(xt[2 * kk], xt[2 * kk + 1], bf[0]);
-      split_kstep<1, NKK, 0, MPNN_NT>(W1s, kk, lane, bf, h1);
-    }
+  for (int t = 0; t < MPNN_NT; ++t) p[t] = row_tile(Pi, t);
 #pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t) h1[t][0] = h1[t][0] * sc + row_tile(Pi, t);
-    BFrag hb[NKK][1];
-    tile_to_bfrag<MPNN_NT, 1, true>(h1, hb);
-    f32x4 y[MPNN_NT][1];
+  for (int kk = 0; kk < NKK; ++kk) {
+    BFrag bf[1];
+    split_pair(xt[2 * kk], xt[2 * kk + 1], bf[0]);
+    split_kstep<1, NKK, 0, MPNN_NT>(W1s, kk, lane, bf, h1);
+  }
 #pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t) y[t][0] = *reinterpret_cast<const f32x4*>(b2 + 16 * t + 4 * g);
+  for (int t = 0; t < MPNN_NT; ++t) h1[t][0] = h1[t][0] * it.sc + p[t];
+  BFrag hb[NKK][1];
+  tile_to_bfrag<MPNN_NT, 1, true>(h1, hb);
+  f32x4 y[MPNN_NT][1];
 #pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) split_kstep<1, NKK, 0, MPNN_NT>(W2s, kk, lane, hb[kk], y);
+  for (int t = 0; t < MPNN_NT; ++t) y[t][0] = *reinterpret_cast<const f32x4*>(b2 + 16 * t + 4 * g);
 #pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t) {
-      f32x4 sm = gelu4(y[t][0]) * w;
-      sm.x = column_sum(sm.x); sm.y = column_sum(sm.y); sm.z = column_sum(sm.z); sm.w = column_sum(sm.w);
-      if (col == 0) {
+  for (int kk = 0; kk < NKK; ++kk) split_kstep<1, NKK, 0, MPNN_NT>(W2s, kk, lane, hb[kk], y);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(&gsl[nl][16 * t + 4 * g + r], sm[r]);
-      }
+  for (int t = 0; t < MPNN_NT; ++t) {
+    f32x4 sm = gelu4(y[t][0]) * it.w;
+    sm.x = column_sum(sm.x); sm.y = column_sum(sm.y); sm.z = column_sum(sm.z); sm.w = column_sum(sm.w);
+    if (col == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&gsl[it.nl][16 * t + 4 * g + r], sm[r]);
     }
   }
-  __syncthreads();  // neighbour sums complete; the message weights in LDS are dead from here on
-  // ---- node phase on eight waves: W3 by output tile, the FFN by hidden eighths (64 units: four rows-tiles of W_in,
-  // one 64-column block of W_out, packed as eight [8][2] matrices by the host), projections by halves
-  constexpr int NODE_WAVES = 8;
-  f32x4 (*ex)[MPNN_NT][64] = reinterpret_cast<f32x4 (*)[MPNN_NT][64]>(lds);  // [NODE_WAVES][8][64] x 16 B = 64 KiB
-  const bool act = wave < NODE_WAVES;
-  const int idx = tile * LV_NODES + col;
-  const bool live = col < LV_NODES && idx < n_list;
+}
+
+// W3's fragments of a node wave (output tile = wave): NKK (hi, lo) pairs, loaded ahead of the message phase
+struct W3Frags {
+  h8 hi[NKK], lo[NKK];
+};
+__device__ __forceinline__ void w3_prefetch(W3Frags& f, const h8* __restrict__ W3) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const h8* Wl = W3 + (size_t)wave * NKK * 2 * 64 + lane;
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) {
+    f.hi[kk] = Wl[(kk * 2 + 0) * 64];
+#ifndef MPNN_FAST
+    f.lo[kk] = Wl[(kk * 2 + 1) * 64];
+#endif
+  }
+}
+
+// node phase on eight waves: W3 by output tile, the FFN by hidden eighths (64 units: four rows-tiles of W_in, one
+// 64-column block of W_out, packed as eight [8][2] matrices by the host), projections by halves.  ex = the exchange
+// buffer [NODE_WAVES][8][64] x 16 B = 64 KiB laid over the (dead) first message weight matrix in LDS.
+constexpr int LV_NODE_WAVES = 8;
+__device__ __forceinline__ void
+level_node(h8* lds, float (*gsl)[MPNN_H], const W3Frags& w3, const int* __restrict__ node_list, int n_list, int tile, int lvn,
+           const float* __restrict__ mask, const float* hV_in, float cnt_const, const float* __restrict__ b3,
+           const float* __restrict__ ln1w, const float* __restrict__ ln1b, const h8* __restrict__ Win,
+           const float* __restrict__ bin, const h8* __restrict__ Wout, const float* __restrict__ bout,
+           const float* __restrict__ ln2w, const float* __restrict__ ln2b, float inv_scale,
+           const h8* __restrict__ Wproj, const float* __restrict__ bproj, int nproj, float* hV_out, float* PQ) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  f32x4 (*ex)[MPNN_NT][64] = reinterpret_cast<f32x4 (*)[MPNN_NT][64]>(lds);
+  const bool act = wave < LV_NODE_WAVES;
+  const int idx = tile * lvn + col;
+  const bool live = col < lvn && idx < n_list;
   const int nd = node_list[live ? idx : n_list - 1];
   f32x4 h[MPNN_NT][1], o[MPNN_NT][1];
   BFrag xb[NKK][1];
@@ -833,10 +875,10 @@ k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, 
       gs[t][0] = *reinterpret_cast<const f32x4*>(&gsl[col][16 * t + 4 * g]);
     }
     tile_to_bfrag<MPNN_NT, 1, false>(gs, xb);
-    f32x4 d1[1][1];
-    d1[0][0] = *reinterpret_cast<const f32x4*>(b3 + 16 * wave + 4 * g) * cnt_const;
-    split_gemm_stream<1, NKK, 1, 3>(W3 + (size_t)wave * NKK * 2 * 64 + lane, xb, d1);
-    ex[0][wave][lane] = d1[0][0];
+    f32x4 d1 = *reinterpret_cast<const f32x4*>(b3 + 16 * wave + 4 * g) * cnt_const;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) d1 = mfma_split(w3.hi[kk], w3.lo[kk], xb[kk][0], d1);
+    ex[0][wave][lane] = d1;
   }
   __syncthreads();
   if (act) {
@@ -877,7 +919,7 @@ k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, 
     BFrag pb[NKK][1];
     tile_to_bfrag<MPNN_NT, 1, false>(h, pb);
     const int ld = nproj * MPNN_H;
-    for (int u = wave; u < 2 * nproj; u += NODE_WAVES) {
+    for (int u = wave; u < 2 * nproj; u += LV_NODE_WAVES) {
       const int p = u >> 1, t0 = 4 * (u & 1);
       f32x4 y[4][1];
 #pragma unroll
@@ -892,11 +934,177 @@ k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, 
   }
 }
 
+__global__ void __launch_bounds__(MPNN_MSGT_WAVES * 64)
+k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp, int offP,
+                  const float* __restrict__ Abuf, int lda, int offA, const float* __restrict__ Bbuf, int ldb, int offB,
+                  const int* __restrict__ rank, const int* __restrict__ E_idx, const float* __restrict__ mask,
+                  const float* __restrict__ edge_mask, const h8* __restrict__ W1b, const h8* __restrict__ W2,
+                  const float* __restrict__ b2, const int* __restrict__ node_list, int n_list, int enc_mod, int L, int K,
+                  int KT, const float* __restrict__ hV_in, float cnt_const, const h8* __restrict__ W3,
+                  const float* __restrict__ b3, const float* __restrict__ ln1w, const float* __restrict__ ln1b,
+                  const h8* __restrict__ Win, const float* __restrict__ bin, const h8* __restrict__ Wout,
+                  const float* __restrict__ bout, const float* __restrict__ ln2w, const float* __restrict__ ln2b,
+                  float inv_scale, const h8* __restrict__ Wproj, const float* __restrict__ bproj, int nproj,
+                  float* __restrict__ hV_out, float* __restrict__ PQ, int lvn) {
+  __shared__ h8 lds[2 * WSPLIT];
+  __shared__ float gsl[16][MPNN_H];
+  const int tile = blockIdx.x;
+  const int nlive = min(lvn, n_list - tile * lvn);
+  // MPNN_ABL_LEVEL_*: timing-only ablation builds (never shipped): what each phase of a level costs
+#ifndef MPNN_ABL_LEVEL_NOFILL
+  lds_fill(lds, W1b, WSPLIT);
+  lds_fill(lds + WSPLIT, W2, WSPLIT);
+#endif
+  for (int i = threadIdx.x; i < 16 * MPNN_H; i += blockDim.x) (&gsl[0][0])[i] = 0.f;
+  LevelItem it;
+  level_item_setup(it, hE, rank, E_idx, mask, edge_mask, node_list, tile, lvn, nlive, enc_mod, L, K, KT);
+  f32x4 xt[MPNN_NT], h1[MPNN_NT][1];
+  level_rows_load(it, Abuf, lda, offA, Bbuf, ldb, offB, xt, h1);
+  W3Frags w3;
+  if ((threadIdx.x >> 6) < LV_NODE_WAVES) w3_prefetch(w3, W3);
+  __syncthreads();
+#ifndef MPNN_ABL_LEVEL_NOMSG
+  if (it.has) level_message(it, lds, lds + WSPLIT, b2, Pbuf, ldp, offP, xt, h1, gsl);
+#else
+  if (it.has && xt[0].x == 123.f && h1[1][0].x == 7.f) gsl[0][0] = 1.f;
+#endif
+  __syncthreads();  // neighbour sums complete; the message weights in LDS are dead from here on
+#ifndef MPNN_ABL_LEVEL_NONODE
+  level_node(lds, gsl, w3, node_list, n_list, tile, lvn, mask, hV_in, cnt_const, b3, ln1w, ln1b, Win, bin, Wout, bout, ln2w,
+             ln2b, inv_scale, Wproj, bproj, nproj, hV_out, PQ);
+#else
+  if (w3.hi[0][0] == (_Float16)77.f && gsl[1][1] == 5.f) hV_out[0] = 1.f;
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// A whole dependency level in ONE launch: within a level a residue's decoder layers and its draw read only residues
+// of EARLIER levels (their rows were finished by earlier launches) and its own rows, so a workgroup takes its tile of
+// LV_NODES residues through every layer and then through the sampling head (mpnn_sample.h).  What a layer costs a
+// level is its chain of dependent memory operations, so everything that does not depend on the previous layer is
+// taken off that chain: the item's indices and its split hE tile are set up once; a layer's gathered neighbour rows
+// and its W3 fragments are in flight before its message weights are staged; while eight waves run a layer's node
+// phase the other four stage the NEXT layer's second message matrix into the half of LDS the exchange buffer does not
+// cover.  The tile's own P / hV rows travel between layers through global memory, ordered by workgroup barriers.
+// Replaces n_layers + 1 dependent launches per level.
+// ---------------------------------------------------------------------------
+#include "mpnn_sample.h"
+
+struct LevelLayer {  // one decoder layer of the device-side plan (mpnn_decode_plan writes it)
+  const float* P; int ldp, offP;
+  float* A; int lda, offA;
+  int offEnc;
+  const h8 *W1b, *W2; const float* b2;
+  const float* hV_in;
+  const h8* W3; const float *b3, *ln1w, *ln1b;
+  const h8* Win; const float* bin;
+  const h8* Wout; const float *bout, *ln2w, *ln2b;
+  float inv_scale;
+  const h8* Wproj; const float* bproj; int nproj;
+  float* hV_out; float* PQ;
+};
+static_assert(sizeof(LevelLayer) * 4 <= MPNN_DECODE_PLAN_BYTES, "mpnn_hip.h: MPNN_DECODE_PLAN_BYTES too small");
+
+__global__ void __launch_bounds__(MPNN_MSGT_WAVES * 64)
+k_decode_level(const f32x4* __restrict__ hE, const float* __restrict__ PVenc, int ldenc, const int* __restrict__ rank,
+               const int* __restrict__ E_idx, const float* __restrict__ mask, const float* __restrict__ edge_mask,
+               const int* __restrict__ node_list, int n_list, int enc_mod, int L, int K, int KT, float cnt_const,
+               const LevelLayer* __restrict__ plan, int n_layers, const f32x4* __restrict__ Wlogit,
+               const float* __restrict__ blogit,
+               const float* __restrict__ logit_bias, int n_letters, float inv_temperature, unsigned long long seed,
+               const float* __restrict__ designable, const long long* __restrict__ S_in, long long* __restrict__ S_out,
+               float* __restrict__ log_probs, const float* __restrict__ TS, int ld_ts, int lvn) {
+  __shared__ h8 lds_base[2 * WSPLIT];
+  __shared__ float gsl_base[16][MPNN_H];
+  __shared__ float pr[16][33];
+  __shared__ int pick[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x;
+  const int nlive = min(lvn, n_list - tile * lvn);
+  STAMP_DECL;
+#ifdef MPNN_STAMP
+  const long long rt0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz constant clock: slot 7 = shader clocks per 100 MHz tick
+#endif
+  LevelItem it;
+  level_item_setup(it, hE, rank, E_idx, mask, edge_mask, node_list, tile, lvn, nlive, enc_mod, L, K, KT);
+  STAMP(0);
+  for (int l = 0; l < n_layers; ++l) {
+    const LevelLayer y = plan[l];  // uniform: scalar loads
+    // an opaque zero in every LDS address of the iteration: without it the ~100 (lane, constant) address sums of the
+    // body are hoisted out of the layer loop and live - spilled to scratch - across it
+    int zero;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    h8* lds = lds_base + zero;
+    float (*gsl)[MPNN_H] = gsl_base + zero;
+    f32x4 xt[MPNN_NT], h1[MPNN_NT][1];
+    level_rows_load(it, y.A, y.lda, y.offA, PVenc, ldenc, y.offEnc, xt, h1);
+    W3Frags w3;
+    if (wave < LV_NODE_WAVES) w3_prefetch(w3, y.W3);
+    lds_fill(lds, y.W1b, WSPLIT);
+    if (l == 0) lds_fill(lds + WSPLIT, y.W2, WSPLIT);  // later layers: staged during the previous node phase
+    for (int i = threadIdx.x; i < 16 * MPNN_H; i += blockDim.x) (&gsl[0][0])[i] = 0.f;
+    __syncthreads();
+    STAMP(1);
+    if (it.has) level_message(it, lds, lds + WSPLIT, y.b2, y.P, y.ldp, y.offP, xt, h1, gsl);
+    STAMP(2);
+    __syncthreads();  // neighbour sums complete; the message weights in LDS are dead from here on
+    STAMP(3);
+    if (wave >= LV_NODE_WAVES && l + 1 < n_layers) {
+      // the four waves without node work stage the next layer's W2 (upper half of lds; ex covers the lower half)
+      const h8* src = plan[l + 1].W2;
+      constexpr int NT = (MPNN_MSGT_WAVES - LV_NODE_WAVES) * 64;
+      const int t0 = threadIdx.x - LV_NODE_WAVES * 64;
+      for (int i0 = t0; i0 < WSPLIT; i0 += 8 * NT) {
+        h8 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[i0 + u * NT];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lds[WSPLIT + i0 + u * NT] = v[u];
+      }
+    }
+    level_node(lds, gsl, w3, node_list, n_list, tile, lvn, mask, y.hV_in, cnt_const, y.b3, y.ln1w, y.ln1b, y.Win, y.bin,
+               y.Wout, y.bout, y.ln2w, y.ln2b, y.inv_scale, y.Wproj, y.bproj, y.nproj, y.hV_out, y.PQ);
+    STAMP(4);
+    // the tile's hV / P rows written above are read by the next layer (or the head) of this workgroup, and the next
+    // layer's LDS fill overwrites the exchange buffer
+    __threadfence_block();
+    __syncthreads();
+    STAMP(5);
+  }
+  if (wave == 0) {
+    const int col = lane & 15, idx = tile * lvn + col;
+    const bool live = col < lvn && idx < n_list;
+    const int nd = node_list[live ? idx : n_list - 1];
+    sample_columns(plan[n_layers - 1].hV_out, Wlogit, blogit, logit_bias, n_letters, nd, live, inv_temperature, seed,
+                   designable, S_in, S_out, log_probs, pr, pick, lane);
+  }
+  __syncthreads();
+  fold_sequence_rows<MPNN_MSGT_WAVES, 2>([&](int l, int n) { return plan[l].A + (size_t)n * plan[l].lda + plan[l].offA; },
+                                         n_layers, TS, ld_ts, node_list + tile * lvn, nlive, pick, wave, lane);
+  STAMP(6);
+#ifdef MPNN_STAMP
+  st_acc[7] = (unsigned long long)(__builtin_amdgcn_s_memrealtime() - rt0);
+#endif
+  if (threadIdx.x < 64) STAMP_FLUSH(0);  // wave 0 takes part in every phase: its clock is the level's timeline
+}
+
 MPNN_KERNELS_END
 
 // ===========================================================================
 // C ABI launchers
 // ===========================================================================
+// residues per workgroup of the level kernels: a level is latency-bound, so while the chip has idle CUs every residue
+// gets a workgroup of its own (its three message items then run on three SIMDs instead of sharing one with eight
+// others); large levels (many samples) share workgroups so that the per-workgroup weight streams stay affordable
+#ifndef MPNN_LEVEL_SPREAD
+#define MPNN_LEVEL_SPREAD 128
+#endif
+static int level_nodes_per_wg(int n_list) {
+  if (n_list <= MPNN_LEVEL_SPREAD) return 1;
+  if (n_list <= 2 * MPNN_LEVEL_SPREAD) return 2;
+  return LV_NODES;
+}
+
 extern "C" int MPNN_API(mpnn_enc_message)(const float* hE_frag, const float* PQ, int ldpq, int offP, int offQ,
                                 const int32_t* E_idx32, const float* mask, const float* edge_mask,
                                 const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K,
@@ -1004,6 +1212,72 @@ extern "C" int MPNN_API(mpnn_dec_message_shared)(const float* hE_frag, const flo
                             mask, edge_mask, W1b_packed, W2_packed, b2, B, n_struct, L, K, gsum, stream);
 }
 
+// Device-side plan of the one-launch-per-level decoder: the layer table is DATA the kernel reads with scalar loads
+// (a by-value kernel argument indexed by the layer would be copied to scratch).  Validated and uploaded once per
+// sampling call; plan_dev: MPNN_DECODE_PLAN_BYTES of device memory the caller owns.
+extern "C" int MPNN_API(mpnn_decode_plan)(const mpnn_level_layer* layers, int n_layers, void* plan_dev, void* stream) {
+  MPNN_CHECK_ARG(layers && plan_dev && n_layers >= 1 && n_layers <= 4, "mpnn_decode_plan: need 1..4 layers and a plan buffer");
+  LevelLayer tab[4] = {};
+  for (int l = 0; l < n_layers; ++l) {
+    const mpnn_level_layer& y = layers[l];
+    MPNN_CHECK_ARG(y.P && y.RowA && y.W1b_packed && y.W2_packed && y.b2 && y.hV_in && y.W3_packed && y.b3 && y.ln1_w &&
+                       y.ln1_b && y.Win_packed && y.b_in && y.Wout8_packed && y.b_out && y.ln2_w && y.ln2_b && y.hV_out,
+                   "mpnn_decode_plan: null pointer in a layer");
+    MPNN_CHECK_ARG(y.scale != 0.f && y.nproj >= 0 && (y.nproj == 0 || (y.Wproj_packed && y.bproj && y.PQ)) &&
+                       mult4(y.ldp, y.offP, y.lda, y.offA, y.offEnc),
+                   "mpnn_decode_plan: bad layer (strides/offsets multiples of 4 floats; projections need Wproj, bproj, PQ)");
+    // a layer's input rows must be the previous layer's outputs: the kernel orders them only within a workgroup
+    MPNN_CHECK_ARG(l == 0 || (y.hV_in == layers[l - 1].hV_out && layers[l - 1].nproj >= 2),
+                   "mpnn_decode_plan: layer l must read the hV rows (and Pa | A projections) layer l-1 writes");
+    LevelLayer& z = tab[l];
+    z.P = y.P; z.ldp = y.ldp; z.offP = y.offP;
+    z.A = y.RowA; z.lda = y.lda; z.offA = y.offA;
+    z.offEnc = y.offEnc;
+    z.W1b = (const h8*)y.W1b_packed; z.W2 = (const h8*)y.W2_packed; z.b2 = y.b2;
+    z.hV_in = y.hV_in;
+    z.W3 = (const h8*)y.W3_packed; z.b3 = y.b3; z.ln1w = y.ln1_w; z.ln1b = y.ln1_b;
+    z.Win = (const h8*)y.Win_packed; z.bin = y.b_in;
+    z.Wout = (const h8*)y.Wout8_packed; z.bout = y.b_out; z.ln2w = y.ln2_w; z.ln2b = y.ln2_b;
+    z.inv_scale = 1.0f / y.scale;
+    z.Wproj = (const h8*)y.Wproj_packed; z.bproj = y.bproj; z.nproj = y.nproj;
+    z.hV_out = y.hV_out; z.PQ = y.PQ;
+  }
+  const hipError_t e = hipMemcpyAsync(plan_dev, tab, sizeof(tab), hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    mpnn_set_error(hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+// One dependency level of the sampler in one launch (k_decode_level)
+extern "C" int MPNN_API(mpnn_decode_level)(const float* hE_frag, const float* PVenc, int ldenc, const int32_t* rank,
+                                 const int32_t* E_idx32, const float* mask, const float* edge_mask,
+                                 const int32_t* node_list, int n_list, int enc_nodes, int L, int K, float cnt_const,
+                                 const void* plan_dev, int n_layers, const float* Wlogit_packed,
+                                 const float* logit_b, const float* logit_bias, int n_letters, float temperature,
+                                 uint64_t seed, const float* designable, const int64_t* S_in, int64_t* S_out,
+                                 float* log_probs, const float* TS, int ld_ts, void* stream) {
+  MPNN_CHECK_ARG(hE_frag && PVenc && rank && E_idx32 && mask && node_list && plan_dev && Wlogit_packed && logit_b &&
+                     designable && S_in && S_out && log_probs && TS,
+                 "mpnn_decode_level: null pointer");
+  MPNN_CHECK_ARG(n_list > 0 && L > 0 && enc_nodes > 0 && enc_nodes % L == 0 && K >= 1 && K <= 48 && n_layers >= 1 &&
+                     n_layers <= 4 && n_letters >= 1 && n_letters <= 32 && temperature > 0.f && (ldenc & 3) == 0 &&
+                     (ld_ts & 3) == 0,
+                 "mpnn_decode_level: bad sizes (K <= 48, 1..4 decoder layers, n_letters <= 32, temperature > 0)");
+  const int KT = (K + 15) / 16;
+#ifdef MPNN_STAMP
+  stamp_report("decode level: setup | rows+fill | message | wait | node | fence | head", 0);
+#endif
+  const int lvn = level_nodes_per_wg(n_list);
+  hipLaunchKernelGGL(k_decode_level, dim3(ceil_div(n_list, lvn)), dim3(MPNN_MSGT_WAVES * 64), 0, (hipStream_t)stream,
+                     (const f32x4*)hE_frag, PVenc, ldenc, rank, E_idx32, mask, edge_mask, node_list, n_list, enc_nodes, L,
+                     K, KT, cnt_const, (const LevelLayer*)plan_dev, n_layers, (const f32x4*)Wlogit_packed, logit_b,
+                     logit_bias, n_letters, 1.0f / temperature, (unsigned long long)seed, designable,
+                     (const long long*)S_in, (long long*)S_out, log_probs, TS, ld_ts, lvn);
+  MPNN_LAUNCH_CHECK();
+}
+
 // ---- training forward: same kernels, pre-activations saved for mpnn_edge_bwd.hip (K <= 48) ----
 #ifndef MPNN_FAST
 extern "C" int mpnn_message_train(int dec, const float* hE_frag, const float* P, const float* RowA, const float* RowB,
@@ -1098,11 +1372,12 @@ extern "C" int MPNN_API(mpnn_dec_layer_subset)(const float* hE_frag, const float
                      mult4(ldp, offP, lda, offA, ldenc, offEnc),
                  "mpnn_dec_layer_subset: bad sizes (K <= 48; strides/offsets multiples of 4 floats)");
   const int KT = (K + 15) / 16;
-  hipLaunchKernelGGL(k_dec_layer_level, dim3(ceil_div(n_list, LV_NODES)), dim3(MPNN_MSGT_WAVES * 64), 0, (hipStream_t)stream,
+  const int lvn = level_nodes_per_wg(n_list);
+  hipLaunchKernelGGL(k_dec_layer_level, dim3(ceil_div(n_list, lvn)), dim3(MPNN_MSGT_WAVES * 64), 0, (hipStream_t)stream,
                      (const f32x4*)hE_frag, P, ldp, offP, RowA, lda, offA, PVenc, ldenc, offEnc, rank, E_idx32, mask,
                      edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2, node_list, n_list, enc_nodes, L, K, KT,
                      hV_in, cnt_const, (const h8*)W3_packed, b3, ln1_w, ln1_b, (const h8*)Win_packed, b_in,
                      (const h8*)Wout_packed, b_out, ln2_w, ln2_b, 1.0f / scale, (const h8*)Wproj_packed, bproj, nproj,
-                     hV_out, PQ);
+                     hV_out, PQ, lvn);
   MPNN_LAUNCH_CHECK();
 }

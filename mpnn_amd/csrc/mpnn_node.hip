@@ -435,26 +435,9 @@ extern "C" int MPNN_API(mpnn_node_update_subset)(const float* hV_in, float* gsum
 MPNN_KERNELS_BEGIN
 // ---------------------------------------------------------------------------
 // Sampling head for a listed subset of residues (one workgroup = 16 residues: wave 0 draws, all four waves fold
-// the sequence terms into the gathered rows):
-//   logits = W_out h + b;  log_probs = log_softmax(logits)  (the model's distribution, what a teacher-forced
-//   forward returns at this position);  S ~ softmax((logits + bias) / temperature)  by inverse CDF with a
-//   counter-based uniform u(seed, residue);  fixed residues (designable[n] == 0) keep S_in[n].
-//   Then the residue's sequence term is folded into the decoder's gathered rows: A_l[n] += TS[S][128 l ..] for
-//   every decoder layer l (reference h_S = W_s(S) enters W1 through h_ES, :478-479, :513).
+// the sequence terms into the gathered rows); the arithmetic is in mpnn_sample.h.
 // ---------------------------------------------------------------------------
-struct SampleRows {
-  float* A[4];
-  int ld[4], off[4];
-  int n_layers;
-};
-
-__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long ctr) {
-  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1);  // splitmix64
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (float)(z >> 40) * (1.0f / 16777216.0f);  // 24 bits -> [0, 1)
-}
+#include "mpnn_sample.h"
 
 __global__ void __launch_bounds__(256)
 k_sample(const float* __restrict__ hV, const f32x4* __restrict__ Wp, const float* __restrict__ bias,
@@ -462,124 +445,23 @@ k_sample(const float* __restrict__ hV, const f32x4* __restrict__ Wp, const float
          float inv_temperature, unsigned long long seed, const float* __restrict__ designable,
          const long long* __restrict__ S_in, long long* __restrict__ S_out, float* __restrict__ log_probs,
          const float* __restrict__ TS, int ld_ts, SampleRows rows) {
-  __shared__ float pr[1][16][33];
-  __shared__ int pick[1][16];
+  __shared__ float pr[16][33];
+  __shared__ int pick[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int wv = 0;
   const int tile = blockIdx.x;  // host: grid = ceil(N / 16), so tile * 16 < N
-  const int g = lane >> 4, col = lane & 15;
   if (wave == 0) {
-  const int idx = tile * 16 + col;
-  const bool live = idx < N;
-  const int nd = node_list[live ? idx : N - 1];
-  f32x4 h[MPNN_NT][1], y[2][1];
-#pragma unroll
-  for (int t = 0; t < MPNN_NT; ++t) h[t][0] = *reinterpret_cast<const f32x4*>(hV + (size_t)nd * MPNN_H + 16 * t + 4 * g);
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int letter = 16 * t + 4 * g + r;
-      y[t][0][r] = letter < n_letters ? bias[letter] : 0.f;
-    }
-#ifndef MPNN_ABL_SAMPLE_NOGEMM
-  tile_gemm<1, MPNN_NT, 0, 2>(Wp, lane, h, y);
-#endif
-  // model log-probs
-  float mx = -INFINITY;
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (16 * t + 4 * g + r < n_letters) mx = fmaxf(mx, y[t][0][r]);
-  mx = fmaxf(mx, __shfl_xor(mx, 16));
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  float se = 0.f;
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (16 * t + 4 * g + r < n_letters) se += expf(y[t][0][r] - mx);
-  se = quarter_sum(se);
-  const float lse = mx + logf(se);
-  // tempered, biased weights for the draw
-  float z[2][4], zm = -INFINITY;
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int letter = 16 * t + 4 * g + r;
-      if (letter < n_letters) {
-        if (live) log_probs[(size_t)nd * n_letters + letter] = y[t][0][r] - lse;
-        z[t][r] = (y[t][0][r] + (logit_bias ? logit_bias[letter] : 0.f)) * inv_temperature;
-        zm = fmaxf(zm, z[t][r]);
-      }
-    }
-  zm = fmaxf(zm, __shfl_xor(zm, 16));
-  zm = fmaxf(zm, __shfl_xor(zm, 32));
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int letter = 16 * t + 4 * g + r;
-      if (letter < n_letters) pr[wv][col][letter] = expf(z[t][r] - zm);
-    }
-  __builtin_amdgcn_s_waitcnt(0);
-  __builtin_amdgcn_wave_barrier();
-  if (g == 0) {
-    int s = 0;
-#ifdef MPNN_ABL_SAMPLE_NOLOOP
-    if (false) {
-#else
-    if (designable[nd] != 0.f) {
-#endif
-      float tot = 0.f;
-      for (int a = 0; a < n_letters; ++a) tot += pr[wv][col][a];
-      const float u = uniform01(seed, (unsigned long long)nd) * tot;
-      float acc = 0.f;
-      s = n_letters - 1;
-      for (int a = 0; a < n_letters; ++a) {
-        acc += pr[wv][col][a];
-        if (u < acc) { s = a; break; }
-      }
-    } else {
-      s = (int)S_in[nd];
-    }
-    pick[wv][col] = s;
-    if (live) S_out[nd] = s;
+    const int idx = tile * 16 + (lane & 15);
+    const bool live = idx < N;
+    const int nd = node_list[live ? idx : N - 1];
+    sample_columns(hV, Wp, bias, logit_bias, n_letters, nd, live, inv_temperature, seed, designable, S_in, S_out,
+                   log_probs, pr, pick, lane);
   }
-  }  // wave 0
   __syncthreads();
-  // fold the sequence term of the chosen letter into every decoder layer's A rows (2 floats per lane per row); the
-  // rows belong to this residue alone until later levels gather them, so plain read-modify-write; the 16 x n_layers
-  // row updates are dealt round-robin to the four waves, each with all its loads in flight before the first store
 #ifdef MPNN_ABL_SAMPLE_NOTAIL  // timing-only ablation build: never shipped
   return;
 #endif
-  const int nlive = min(16, N - tile * 16);
-  const int nupd = nlive * rows.n_layers;
-  constexpr int MAXU = 16;  // 16 residues x 4 layers / 4 waves
-  float2 v[MAXU], add[MAXU];
-  float2* dst[MAXU];
-#pragma unroll
-  for (int i = 0; i < MAXU; ++i) {
-    const int u = wave + 4 * i;
-    if (u < nupd) {
-      const int c = u % nlive, l = u / nlive;
-      const int n = node_list[tile * 16 + c], s = pick[wv][c];
-      dst[i] = reinterpret_cast<float2*>(rows.A[l] + (size_t)n * rows.ld[l] + rows.off[l]) + lane;
-      v[i] = *dst[i];
-      add[i] = *(reinterpret_cast<const float2*>(TS + (size_t)s * ld_ts + l * MPNN_H) + lane);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < MAXU; ++i) {
-    if (wave + 4 * i < nupd) {
-      v[i].x += add[i].x;
-      v[i].y += add[i].y;
-      *dst[i] = v[i];
-    }
-  }
+  fold_sequence_rows<4, 16>([&](int l, int n) { return rows.A[l] + (size_t)n * rows.ld[l] + rows.off[l]; },
+                            rows.n_layers, TS, ld_ts, node_list + tile * 16, min(16, N - tile * 16), pick, wave, lane);
 }
 
 MPNN_KERNELS_END

@@ -203,8 +203,8 @@ class NumericsGuard:
         self.next = 0
 
     def watch(self, t, what):
-        if torch.cuda.is_current_stream_capturing():
-            return
+        if torch.cuda.is_current_stream_capturing() or os.environ.get("MPNN_NO_NUMERICS_GUARD") == "1":
+            return  # (the switch is for timing-only ablation builds of the library, whose outputs are garbage)
         call("mpnn_range_flag", ptr(t), t.numel(), float("inf"), ptr(self.flag), 1, stream_ptr())
         if len(self.pending) >= self.SLOTS:
             self.poll(block=True)
@@ -750,24 +750,56 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
         head = [ptr(hVs[n_dec]), ptr(pw.Wlogit), ptr(pw.blogit), ptr(lb), pw.n_letters, None, 0, float(temperature),
                 int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(designable), ptr(S_in), ptr(S_out), ptr(log_probs), ptr(pw.TS),
                 pw.TS.shape[1], n_dec, A_rows, A_ld, A_off, st]
-        fused = os.environ.get("MPNN_SAMPLE_UNFUSED") != "1"  # one launch per decoder layer and level
+        # MPNN_SAMPLE_LAUNCHES: "layer" (default) = one launch per decoder layer and level plus the head; "level" = one
+        # launch per level (mpnn_decode_level; measured SLOWER on MI355X: 101 us per level against 3 x 23 + 10.5 us,
+        # DESIGN.md section 8b); "split" = message / node update / head launches
+        mode = os.environ.get("MPNN_SAMPLE_LAUNCHES", "layer")
+        if os.environ.get("MPNN_SAMPLE_UNFUSED") == "1":
+            mode = "split"
         f_layer = getattr(lib, _lib.entry("mpnn_dec_layer_subset"))
         f_msg = getattr(lib, _lib.entry("mpnn_dec_message_subset"))
         f_node = getattr(lib, _lib.entry("mpnn_node_update_subset"))
         f_head = lib.mpnn_sample_subset
+        f_level = getattr(lib, _lib.entry("mpnn_decode_level"))
         if _lib._profile is not None:  # bench.py's per-entry-point timing goes through the generic wrapper
             f_layer = lambda *a: (call("mpnn_dec_layer_subset", *a), 0)[1]
             f_msg = lambda *a: (call("mpnn_dec_message_subset", *a), 0)[1]
             f_node = lambda *a: (call("mpnn_node_update_subset", *a), 0)[1]
             f_head = lambda *a: (call("mpnn_sample_subset", *a), 0)[1]
+            f_level = lambda *a: (call("mpnn_decode_level", *a), 0)[1]
+        layers = (_lib.LevelLayer * n_dec)()
+        for l, lw in enumerate(pw.dec):
+            grp = pw.g_dec[l]
+            y = layers[l]
+            y.P, y.ldp, y.offP = ptr(PA[l]), 2 * H, 0
+            y.RowA, y.lda, y.offA = ptr(PA[l]), 2 * H, H
+            y.offEnc = base + 2 * H + H * l
+            y.W1b_packed, y.W2_packed, y.b2 = ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"])
+            y.hV_in, y.hV_out = ptr(hVs[l]), ptr(hVs[l + 1])
+            y.W3_packed, y.b3, y.ln1_w, y.ln1_b = ptr(lw["W3"]), ptr(lw["b3"]), ptr(lw["ln1w"]), ptr(lw["ln1b"])
+            y.Win_packed, y.b_in, y.Wout8_packed, y.b_out = ptr(lw["Win"]), ptr(lw["bin"]), ptr(lw["Wout8"]), ptr(lw["bout"])
+            y.ln2_w, y.ln2_b, y.scale = ptr(lw["ln2w"]), ptr(lw["ln2b"]), lw["scale"]
+            y.Wproj_packed, y.bproj, y.nproj = ptr(grp[0]), ptr(grp[1]), grp[2]
+            y.PQ = ptr(PA[l + 1]) if grp[2] else None
+        plan = torch.empty(1024, device=dev, dtype=torch.uint8)  # MPNN_DECODE_PLAN_BYTES
+        if mode == "level":
+            call("mpnn_decode_plan", layers, n_dec, ptr(plan), st)
+        level = [ptr(enc["hE"]), ptr(PQenc), PQenc.shape[1], ptr(rank), ptr(enc["E_idx32"]), ptr(mask_s),
+                 ptr(enc["edge_mask"]), None, 0, N, L, K, float(K), ptr(plan), n_dec, ptr(pw.Wlogit), ptr(pw.blogit), ptr(lb),
+                 pw.n_letters, float(temperature), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(designable), ptr(S_in),
+                 ptr(S_out), ptr(log_probs), ptr(pw.TS), pw.TS.shape[1], st]
         list_ptr = perm.data_ptr()
         start = 0
         rc = 0
         for cnt_l in counts:
             p_nodes = list_ptr + 4 * start
             start += cnt_l
+            if mode == "level":
+                level[7], level[8] = p_nodes, cnt_l
+                rc = rc or f_level(*level)
+                continue
             for msg, node, layer in plans:
-                if fused:
+                if mode == "layer":
                     layer[17], layer[18] = p_nodes, cnt_l
                     rc = rc or f_layer(*layer)
                 else:

@@ -6,7 +6,7 @@ files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in files:
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"].split("(")[0][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in sorted(acc.items(), key=lambda kv: -sum(sum(v) for v in kv[1].values())):
     if k.startswith("void at::") or k.startswith("__amd"): continue
     n = max(len(v) for v in cs.values())
