@@ -164,6 +164,8 @@ int mpnn_dec_message_valid(const float* hE_frag, const float* PQ, int ldpq, int 
  *   P / RowA (ld, off): the layer's Pa | A rows, per sample row; offEnc: column of its encoder rows in PVenc;
  *   hV_in -> hV_out; PQ [.., nproj * 128]: the NEXT layer's Pa | A rows (nproj = 0 for the last layer);
  *   layers[l].hV_in must be layers[l-1].hV_out and layers[l].P / RowA must live in layers[l-1].PQ.
+ * mpnn_decode_level runs layers first_layer .. n_layers-1 and the head (first_layer = 0: the whole level; the layers
+ * before first_layer must then have been run by mpnn_dec_layer_subset on the same list).
  * K <= 48, 1..4 layers, n_letters <= 32. */
 typedef struct mpnn_level_layer {
   const float* P; int ldp, offP;
@@ -183,14 +185,15 @@ int mpnn_decode_plan(const mpnn_level_layer* layers, int n_layers, void* plan_de
 int mpnn_decode_plan_f16(const mpnn_level_layer* layers, int n_layers, void* plan_dev, void* stream);
 int mpnn_decode_level(const float* hE_frag, const float* PVenc, int ldenc, const int32_t* rank, const int32_t* E_idx32,
                       const float* mask, const float* edge_mask, const int32_t* node_list, int n_list, int enc_nodes,
-                      int L, int K, float cnt_const, const void* plan_dev, int n_layers, const float* Wlogit_packed,
+                      int L, int K, float cnt_const, const void* plan_dev, int first_layer, int n_layers,
+                      const float* Wlogit_packed,
                       const float* logit_b, const float* logit_bias, int n_letters, float temperature, uint64_t seed,
                       const float* designable, const int64_t* S_in, int64_t* S_out, float* log_probs, const float* TS,
                       int ld_ts, void* stream);
 int mpnn_decode_level_f16(const float* hE_frag, const float* PVenc, int ldenc, const int32_t* rank,
                           const int32_t* E_idx32, const float* mask, const float* edge_mask, const int32_t* node_list,
-                          int n_list, int enc_nodes, int L, int K, float cnt_const, const void* plan_dev, int n_layers,
-                          const float* Wlogit_packed, const float* logit_b, const float* logit_bias, int n_letters,
+                          int n_list, int enc_nodes, int L, int K, float cnt_const, const void* plan_dev,
+                          int first_layer, int n_layers, const float* Wlogit_packed, const float* logit_b, const float* logit_bias, int n_letters,
                           float temperature, uint64_t seed, const float* designable, const int64_t* S_in,
                           int64_t* S_out, float* log_probs, const float* TS, int ld_ts, void* stream);
 

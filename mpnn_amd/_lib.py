@@ -50,7 +50,7 @@ SIGNATURES = {
     "mpnn_dec_message_valid": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "mpnn_dec_message_shared": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "mpnn_decode_plan": [ctypes.POINTER(LevelLayer), _I, _P, _P],
-    "mpnn_decode_level": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P,
+    "mpnn_decode_level": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P, _P,
                           _I, _F, _U64, _P, _P, _P, _P, _P, _I, _P],
     "mpnn_node_update": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _I,
                          _P, _I, _I, _P, _I, _I, _P, _P, _P],

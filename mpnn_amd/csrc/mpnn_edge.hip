@@ -744,6 +744,27 @@ constexpr int LV_NODES = 4;  // at most; small levels use fewer per workgroup (l
 // ---- pieces of a level kernel.  A workgroup of MPNN_MSGT_WAVES = 12 waves owns LV_NODES = 4 listed residues; with
 // K <= 48 (at most 3 column tiles) that is at most ONE message item (local residue, column tile) per wave.
 
+// a 64 KiB weight matrix on its way into LDS: the loads are issued up front (issue), whatever else the layer has to
+// fetch - index chain, neighbour rows, W3 fragments - is issued behind them, and only then are they written (commit)
+constexpr int LV_FILL = (WSPLIT + MPNN_MSGT_WAVES * 64 - 1) / (MPNN_MSGT_WAVES * 64);
+struct LdsFill {
+  h8 v[LV_FILL];
+};
+__device__ __forceinline__ void lds_fill_issue(LdsFill& f, const h8* __restrict__ src) {
+#pragma unroll
+  for (int u = 0; u < LV_FILL; ++u) {
+    const int i = threadIdx.x + u * (MPNN_MSGT_WAVES * 64);
+    if (i < WSPLIT) f.v[u] = src[i];
+  }
+}
+__device__ __forceinline__ void lds_fill_commit(const LdsFill& f, h8* dst) {
+#pragma unroll
+  for (int u = 0; u < LV_FILL; ++u) {
+    const int i = threadIdx.x + u * (MPNN_MSGT_WAVES * 64);
+    if (i < WSPLIT) dst[i] = f.v[u];
+  }
+}
+
 // what a wave knows about its message item before any layer runs: indices, scale / weight, where its hE tile is
 struct LevelItem {
   bool has, before;
@@ -951,10 +972,9 @@ k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, 
   const int tile = blockIdx.x;
   const int nlive = min(lvn, n_list - tile * lvn);
   // MPNN_ABL_LEVEL_*: timing-only ablation builds (never shipped): what each phase of a level costs
-#ifndef MPNN_ABL_LEVEL_NOFILL
-  lds_fill(lds, W1b, WSPLIT);
-  lds_fill(lds + WSPLIT, W2, WSPLIT);
-#endif
+  LdsFill f1, f2;
+  lds_fill_issue(f1, W1b);
+  lds_fill_issue(f2, W2);
   for (int i = threadIdx.x; i < 16 * MPNN_H; i += blockDim.x) (&gsl[0][0])[i] = 0.f;
   LevelItem it;
   level_item_setup(it, hE, rank, E_idx, mask, edge_mask, node_list, tile, lvn, nlive, enc_mod, L, K, KT);
@@ -962,6 +982,10 @@ k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, 
   level_rows_load(it, Abuf, lda, offA, Bbuf, ldb, offB, xt, h1);
   W3Frags w3;
   if ((threadIdx.x >> 6) < LV_NODE_WAVES) w3_prefetch(w3, W3);
+#ifndef MPNN_ABL_LEVEL_NOFILL
+  lds_fill_commit(f1, lds);
+  lds_fill_commit(f2, lds + WSPLIT);
+#endif
   __syncthreads();
 #ifndef MPNN_ABL_LEVEL_NOMSG
   if (it.has) level_message(it, lds, lds + WSPLIT, b2, Pbuf, ldp, offP, xt, h1, gsl);
@@ -1013,7 +1037,7 @@ k_decode_level(const f32x4* __restrict__ hE, const float* __restrict__ PVenc, in
                const float* __restrict__ blogit,
                const float* __restrict__ logit_bias, int n_letters, float inv_temperature, unsigned long long seed,
                const float* __restrict__ designable, const long long* __restrict__ S_in, long long* __restrict__ S_out,
-               float* __restrict__ log_probs, const float* __restrict__ TS, int ld_ts, int lvn) {
+               float* __restrict__ log_probs, const float* __restrict__ TS, int ld_ts, int lvn, int first_layer) {
   __shared__ h8 lds_base[2 * WSPLIT];
   __shared__ float gsl_base[16][MPNN_H];
   __shared__ float pr[16][33];
@@ -1026,9 +1050,8 @@ k_decode_level(const f32x4* __restrict__ hE, const float* __restrict__ PVenc, in
   const long long rt0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz constant clock: slot 7 = shader clocks per 100 MHz tick
 #endif
   LevelItem it;
-  level_item_setup(it, hE, rank, E_idx, mask, edge_mask, node_list, tile, lvn, nlive, enc_mod, L, K, KT);
   STAMP(0);
-  for (int l = 0; l < n_layers; ++l) {
+  for (int l = first_layer; l < n_layers; ++l) {
     const LevelLayer y = plan[l];  // uniform: scalar loads
     // an opaque zero in every LDS address of the iteration: without it the ~100 (lane, constant) address sums of the
     // body are hoisted out of the layer loop and live - spilled to scratch - across it
@@ -1036,12 +1059,18 @@ k_decode_level(const f32x4* __restrict__ hE, const float* __restrict__ PVenc, in
     asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
     h8* lds = lds_base + zero;
     float (*gsl)[MPNN_H] = gsl_base + zero;
+    LdsFill f1, f2;
+    lds_fill_issue(f1, y.W1b);
+    if (l == first_layer) {  // later layers: W2 was staged during the previous node phase
+      lds_fill_issue(f2, y.W2);
+      level_item_setup(it, hE, rank, E_idx, mask, edge_mask, node_list, tile, lvn, nlive, enc_mod, L, K, KT);
+    }
     f32x4 xt[MPNN_NT], h1[MPNN_NT][1];
     level_rows_load(it, y.A, y.lda, y.offA, PVenc, ldenc, y.offEnc, xt, h1);
     W3Frags w3;
     if (wave < LV_NODE_WAVES) w3_prefetch(w3, y.W3);
-    lds_fill(lds, y.W1b, WSPLIT);
-    if (l == 0) lds_fill(lds + WSPLIT, y.W2, WSPLIT);  // later layers: staged during the previous node phase
+    lds_fill_commit(f1, lds);
+    if (l == first_layer) lds_fill_commit(f2, lds + WSPLIT);
     for (int i = threadIdx.x; i < 16 * MPNN_H; i += blockDim.x) (&gsl[0][0])[i] = 0.f;
     __syncthreads();
     STAMP(1);
@@ -1254,7 +1283,7 @@ extern "C" int MPNN_API(mpnn_decode_plan)(const mpnn_level_layer* layers, int n_
 extern "C" int MPNN_API(mpnn_decode_level)(const float* hE_frag, const float* PVenc, int ldenc, const int32_t* rank,
                                  const int32_t* E_idx32, const float* mask, const float* edge_mask,
                                  const int32_t* node_list, int n_list, int enc_nodes, int L, int K, float cnt_const,
-                                 const void* plan_dev, int n_layers, const float* Wlogit_packed,
+                                 const void* plan_dev, int first_layer, int n_layers, const float* Wlogit_packed,
                                  const float* logit_b, const float* logit_bias, int n_letters, float temperature,
                                  uint64_t seed, const float* designable, const int64_t* S_in, int64_t* S_out,
                                  float* log_probs, const float* TS, int ld_ts, void* stream) {
@@ -1262,8 +1291,8 @@ extern "C" int MPNN_API(mpnn_decode_level)(const float* hE_frag, const float* PV
                      designable && S_in && S_out && log_probs && TS,
                  "mpnn_decode_level: null pointer");
   MPNN_CHECK_ARG(n_list > 0 && L > 0 && enc_nodes > 0 && enc_nodes % L == 0 && K >= 1 && K <= 48 && n_layers >= 1 &&
-                     n_layers <= 4 && n_letters >= 1 && n_letters <= 32 && temperature > 0.f && (ldenc & 3) == 0 &&
-                     (ld_ts & 3) == 0,
+                     n_layers <= 4 && first_layer >= 0 && first_layer < n_layers && n_letters >= 1 && n_letters <= 32 &&
+                     temperature > 0.f && (ldenc & 3) == 0 && (ld_ts & 3) == 0,
                  "mpnn_decode_level: bad sizes (K <= 48, 1..4 decoder layers, n_letters <= 32, temperature > 0)");
   const int KT = (K + 15) / 16;
 #ifdef MPNN_STAMP
@@ -1274,7 +1303,7 @@ extern "C" int MPNN_API(mpnn_decode_level)(const float* hE_frag, const float* PV
                      (const f32x4*)hE_frag, PVenc, ldenc, rank, E_idx32, mask, edge_mask, node_list, n_list, enc_nodes, L,
                      K, KT, cnt_const, (const LevelLayer*)plan_dev, n_layers, (const f32x4*)Wlogit_packed, logit_b,
                      logit_bias, n_letters, 1.0f / temperature, (unsigned long long)seed, designable,
-                     (const long long*)S_in, (long long*)S_out, log_probs, TS, ld_ts, lvn);
+                     (const long long*)S_in, (long long*)S_out, log_probs, TS, ld_ts, lvn, first_layer);
   MPNN_LAUNCH_CHECK();
 }
 

@@ -750,9 +750,10 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
         head = [ptr(hVs[n_dec]), ptr(pw.Wlogit), ptr(pw.blogit), ptr(lb), pw.n_letters, None, 0, float(temperature),
                 int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(designable), ptr(S_in), ptr(S_out), ptr(log_probs), ptr(pw.TS),
                 pw.TS.shape[1], n_dec, A_rows, A_ld, A_off, st]
-        # MPNN_SAMPLE_LAUNCHES: "layer" (default) = one launch per decoder layer and level plus the head; "level" = one
-        # launch per level (mpnn_decode_level; measured SLOWER on MI355X: 101 us per level against 3 x 23 + 10.5 us,
-        # DESIGN.md section 8b); "split" = message / node update / head launches
+        # MPNN_SAMPLE_LAUNCHES: "layer" (default) = one launch per decoder layer and level plus the head; "layer+draw" =
+        # the last layer's launch also draws (mpnn_decode_level from the last layer); "level" = one launch per level
+        # (mpnn_decode_level).  Both fused forms measured SLOWER on MI355X (one L = 512 sample: 6.7 ms / 7.3 ms /
+        # 8.1 ms).  "split" = message / node update / head launches
         mode = os.environ.get("MPNN_SAMPLE_LAUNCHES", "layer")
         if os.environ.get("MPNN_SAMPLE_UNFUSED") == "1":
             mode = "split"
@@ -782,10 +783,10 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
             y.Wproj_packed, y.bproj, y.nproj = ptr(grp[0]), ptr(grp[1]), grp[2]
             y.PQ = ptr(PA[l + 1]) if grp[2] else None
         plan = torch.empty(1024, device=dev, dtype=torch.uint8)  # MPNN_DECODE_PLAN_BYTES
-        if mode == "level":
+        if mode in ("level", "layer+draw"):
             call("mpnn_decode_plan", layers, n_dec, ptr(plan), st)
         level = [ptr(enc["hE"]), ptr(PQenc), PQenc.shape[1], ptr(rank), ptr(enc["E_idx32"]), ptr(mask_s),
-                 ptr(enc["edge_mask"]), None, 0, N, L, K, float(K), ptr(plan), n_dec, ptr(pw.Wlogit), ptr(pw.blogit), ptr(lb),
+                 ptr(enc["edge_mask"]), None, 0, N, L, K, float(K), ptr(plan), 0 if mode == "level" else n_dec - 1, n_dec, ptr(pw.Wlogit), ptr(pw.blogit), ptr(lb),
                  pw.n_letters, float(temperature), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(designable), ptr(S_in),
                  ptr(S_out), ptr(log_probs), ptr(pw.TS), pw.TS.shape[1], st]
         list_ptr = perm.data_ptr()
@@ -795,6 +796,13 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
             p_nodes = list_ptr + 4 * start
             start += cnt_l
             if mode == "level":
+                level[7], level[8] = p_nodes, cnt_l
+                rc = rc or f_level(*level)
+                continue
+            if mode == "layer+draw":  # the last layer's launch also draws (mpnn_decode_level from layer n_dec - 1)
+                for msg, node, layer in plans[:-1]:
+                    layer[17], layer[18] = p_nodes, cnt_l
+                    rc = rc or f_layer(*layer)
                 level[7], level[8] = p_nodes, cnt_l
                 rc = rc or f_level(*level)
                 continue

@@ -158,10 +158,10 @@ def test_launch_modes_agree(monkeypatch):
     args = (b["X"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
     for n_samples in (2, 40):
         outs = {}
-        for mode in ("layer", "level", "split"):
+        for mode in ("layer", "layer+draw", "level", "split"):
             monkeypatch.setenv("MPNN_SAMPLE_LAUNCHES", mode)
             outs[mode] = model.sample(*args, S_true=b["S"], n_samples=n_samples, temperature=0.3, seed=7)
-        for other in ("level", "split"):
+        for other in ("layer+draw", "level", "split"):
             same = (outs["layer"]["S"] == outs[other]["S"]).float().mean()
             assert float(same) > 0.99, other  # a draw can flip where u lands within an ulp of a CDF step
             agree = (outs["layer"]["S"] == outs[other]["S"]).all(-1).all(-1)  # samples drawn identically
