@@ -330,6 +330,15 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
   int node = blockIdx.x;
   if (node < N) fetch(node);
   for (; node < N; node += gridDim.x) {
+#ifdef MPNN_ABL_WGRAD_STREAM  // timing-only ablation build (never shipped): the operand streams alone
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (c < KT) acc[tt][c] += va[tt][c] * vb[tt][c];
+    if (node + (int)gridDim.x < N) fetch(node + gridDim.x);
+    continue;
+#endif
     __syncthreads();  // previous residue's operand reads are done
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {

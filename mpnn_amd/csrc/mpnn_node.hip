@@ -21,6 +21,10 @@ MPNN_KERNELS_BEGIN
 constexpr int NKK = MPNN_NT / 2;
 constexpr int WSPLIT = MPNN_NT * NKK * 2 * 64;  // h8 elements of one packed 128x128 split matrix
 
+// fragments of the staged matrix read from LDS ahead of the MFMAs that use them
+#ifndef MPNN_NODE_LDS_RING
+#define MPNN_NODE_LDS_RING 6  // measured: 3 -> 0.335, 6 -> 0.309, 10 / 15 -> 0.309 ms per step (7 launches, B32 x L512)
+#endif
 #ifndef MPNN_NODE_WAVES
 #define MPNN_NODE_WAVES 4  // waves (16-node tiles) per workgroup of k_node_update
 #endif
@@ -100,7 +104,7 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
       }
       tile_to_bfrag<MPNN_NT, 1, false>(gs, xb);
       prefetch();
-      split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT + lane, xb, dh);
+      split_gemm_stream<1, NKK, MPNN_NT, MPNN_NODE_LDS_RING>(lds + (k & 1) * WSPLIT + lane, xb, dh);
       retire();
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t) h[t][0] = h[t][0] + dh[t][0] * inv_scale;
@@ -120,12 +124,12 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
       for (int t = 0; t < MPNN_NT; ++t)
         hid[t][0] = *reinterpret_cast<const f32x4*>(bin + 128 * q + 16 * t + 4 * g);
       prefetch();
-      split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT + lane, xb, hid);
+      split_gemm_stream<1, NKK, MPNN_NT, MPNN_NODE_LDS_RING>(lds + (k & 1) * WSPLIT + lane, xb, hid);
       retire();
       BFrag hb[NKK][1];
       tile_to_bfrag<MPNN_NT, 1, true>(hid, hb);
       prefetch();
-      split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT + lane, hb, o);
+      split_gemm_stream<1, NKK, MPNN_NT, MPNN_NODE_LDS_RING>(lds + (k & 1) * WSPLIT + lane, hb, o);
       retire();
     }
     float mk = 1.0f;
@@ -147,7 +151,7 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) y[t][0] = *reinterpret_cast<const f32x4*>(bproj + p * MPNN_H + 16 * t + 4 * g);
     prefetch();
-    split_gemm_stream<1, NKK, MPNN_NT, 3>(lds + (k & 1) * WSPLIT + lane, pb, y);
+    split_gemm_stream<1, NKK, MPNN_NT, MPNN_NODE_LDS_RING>(lds + (k & 1) * WSPLIT + lane, pb, y);
     retire();
     if (add_table && p == add_block) {  // decoder: fold the sequence term W1c W_s[S_n] into the A block
       const float* tr = add_table + (size_t)add_idx[nd] * ld_table + off_table + 4 * g;
