@@ -32,6 +32,9 @@ CASES = {
                        dict(lengths=[40, 40, 7], seed=9, n_chains=2, unresolved_every=6)),
     "knn20_enc_only": (dict(num_neighbors=20, num_encoder_layers=2, num_decoder_layers=0),
                        dict(lengths=[50], seed=11, unresolved_every=0)),
+    # four column tiles per residue: the tile-wise message kernels (k > 48)
+    "knn64_tiles": (dict(num_neighbors=64, num_encoder_layers=2, num_decoder_layers=2),
+                    dict(lengths=[100, 70], seed=13, n_chains=2, unresolved_every=13)),
 }
 
 
@@ -128,3 +131,22 @@ def test_sparse_at_size_graphs_are_independent():
         alone = model(**one, decoding_order=order[g:g + 1, :lengths[g]] if lengths[g] == 512 else
                       torch.argsort(torch.argsort(order[g:g + 1])[:, :lengths[g]]))
         assert float((alone - lp[sel]).abs().max()) <= 1e-6
+
+
+def test_sparse_f16_products_stay_within_the_reduced_precision_bar():
+    """model.precision = "f16": one f16 product per fp32 product (include/mpnn_hip.h); same bar as the dense model's
+    reduced-precision forward: max |d log p| <= 5e-2 against the fp32-class path, same graph."""
+    from mpnn_amd.sparse import ProteinMPNN
+    from mpnn_amd.synthetic import synthetic_flat_batch
+
+    torch.manual_seed(8)
+    model = randomized(ProteinMPNN(num_neighbors=30), seed=9).eval().to("cuda")
+    b = {k: v.to("cuda") for k, v in synthetic_flat_batch([128, 90], seed=19, n_chains=2).items()}
+    order = b.pop("decoding_order")
+    ref = model(**b, decoding_order=order)
+    model.precision = "f16"
+    low = model(**b, decoding_order=order)
+    model.precision = "fp32"
+    d = float((low - ref).abs().max())
+    assert 0.0 < d <= 5e-2, d
+    assert float((low.argmax(-1) == ref.argmax(-1)).float().mean()) >= 0.97
