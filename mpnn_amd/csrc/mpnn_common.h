@@ -285,9 +285,20 @@ template <int NKK, int NTO, int D>
 __device__ __forceinline__ void wring_load(WRing<D>& r, const h8* __restrict__ Wlane, int q) {
   // Wlane = packed base + lane; fragment (to, kk) lives at ((to * NKK + kk) * 2 + part) * 64
   const int to = q % NTO, kk = q / NTO;
+#if defined(MPNN_ABL_WSTREAM_SAME)  // timing-only ablation builds (never shipped): every fragment read hits the same lines,
+  r.hi[q % (D + 1)] = Wlane[0];     // or no fragment is read at all: what the weight streams of a kernel cost
+  r.lo[q % (D + 1)] = Wlane[64];
+  (void)to; (void)kk;
+#elif defined(MPNN_ABL_WSTREAM_NONE)
+  r.hi[q % (D + 1)] = r.lo[q % (D + 1)] = h8{(_Float16)0.01f, (_Float16)0.02f, (_Float16)0.01f, (_Float16)0.02f,
+                                            (_Float16)0.01f, (_Float16)0.02f, (_Float16)0.01f, (_Float16)0.02f};
+  asm volatile("" : "+v"(r.hi[q % (D + 1)]), "+v"(r.lo[q % (D + 1)]));
+  (void)to; (void)kk; (void)Wlane;
+#else
   r.hi[q % (D + 1)] = Wlane[((to * NKK + kk) * 2 + 0) * 64];
 #ifndef MPNN_FAST
   r.lo[q % (D + 1)] = Wlane[((to * NKK + kk) * 2 + 1) * 64];
+#endif
 #endif
 }
 
