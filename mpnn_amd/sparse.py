@@ -93,9 +93,14 @@ def to_dense_layout(batch: torch.Tensor):
     """`batch` [n] (sorted graph ids, as PyG's knn_graph requires) -> (B, Lmax, slot [n]): node v sits at row
     slot[v] = batch[v] * Lmax + (v - first node of its graph) of the padded [B * Lmax] layout.  One host read (Lmax)."""
     batch = _i64(batch)
+    if batch.numel() == 0:
+        raise ValueError("empty batch")
     counts = torch.bincount(batch)
     B = counts.numel()
-    Lmax = int(counts.max())
+    ordered = (batch[1:] >= batch[:-1]).all() if batch.numel() > 1 else torch.ones((), dtype=torch.bool, device=batch.device)
+    Lmax, ok, lo = torch.stack([counts.max(), ordered.to(counts.dtype), batch.min()]).tolist()  # the one host read
+    if not ok or lo < 0:
+        raise ValueError("`batch` must hold non-negative graph ids in non-decreasing order (as knn_graph requires)")
     first = torch.cumsum(counts, 0) - counts
     slot = batch * Lmax + (torch.arange(batch.numel(), device=batch.device) - first[batch])
     return B, Lmax, slot

@@ -147,3 +147,14 @@ def test_oracle_is_a_distribution_and_ignores_unresolved_coordinates():
     for v in range(26):
         want = min(8, n_valid[int(b["batch"][v])]) if valid[v] else 0
         assert int(deg[v]) == want
+
+
+def test_dense_layout_rejects_unsorted_or_empty_batches():
+    from mpnn_amd.sparse import to_dense_layout
+
+    with pytest.raises(ValueError):
+        to_dense_layout(torch.tensor([0, 1, 0]))
+    with pytest.raises(ValueError):
+        to_dense_layout(torch.zeros(0, dtype=torch.long))
+    B, L, slot = to_dense_layout(torch.tensor([0, 0, 2]))  # an empty graph in between is allowed (bincount gives it 0 nodes)
+    assert (B, L) == (3, 2) and slot.tolist() == [0, 1, 4]
