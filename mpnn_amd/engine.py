@@ -445,6 +445,19 @@ def shared_structures(X, S, mask, residue_idx, chain_encoding_all):
     return X, mask, residue_idx, chain_encoding_all, n
 
 
+def _decoding_rank(chain_M, mask, fix_order, B, L):
+    """decoding order [B, L] (given, or drawn as the reference does, :489-491) and its inverse permutation `rank`."""
+    dev = mask.device
+    chain_M = _f32(chain_M) * mask
+    if fix_order is not None:
+        order = _i64(fix_order)
+    else:  # the argsort of a [B, L] key is host-side plumbing
+        order = torch.argsort((chain_M + 0.0001) * torch.abs(torch.randn(chain_M.shape, device=dev)))
+    rank = torch.zeros(B * L, device=dev, dtype=torch.int32)
+    call("mpnn_order_rank", ptr(order), B, L, ptr(rank), stream_ptr())
+    return order, rank
+
+
 def _forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_order, fix_backbone_noise,
              return_intermediates):
     dev = X.device
@@ -454,12 +467,36 @@ def _forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_or
     S = _i64(S)
     residue_idx, chain_labels = _i64(residue_idx), _i64(chain_encoding_all)
     pw = packed(model)
-    st = stream_ptr()
     fm = model.features
     inter = {}
 
     atoms, _, E_idx64, E_idx32, D_nb, edge_mask, K = _geometry(fm, X, mask, fix_backbone_noise, model.training)
     occ = _occupancy(fm, atoms, mask, B, L)
+    order = rank = None
+    if len(pw.dec):
+        order, rank = _decoding_rank(chain_M, mask, fix_order, B, L)
+    if return_intermediates:
+        inter.update(E_idx=E_idx64, D_neighbors=D_nb, edge_mask=edge_mask, occupancy=occ, h_V_enc=[], h_V_dec=[],
+                     h_E_enc=[])
+        if rank is not None:
+            bw = torch.empty(B, L, K, device=dev, dtype=torch.float32)
+            fw = torch.empty_like(bw)
+            call("mpnn_order_masks", ptr(rank), ptr(E_idx64), ptr(mask), ptr(edge_mask), B, L, K, ptr(bw), ptr(fw),
+                 stream_ptr())
+            inter.update(mask_bw=bw, mask_fw=fw, order=order)
+    log_probs = _layers(pw, B, L, K, atoms, E_idx32, edge_mask, occ, mask, S, residue_idx, chain_labels, rank,
+                        inter if return_intermediates else None)
+    if return_intermediates:
+        inter["log_probs"] = log_probs
+        return inter
+    return log_probs
+
+
+def _layers(pw, B, L, K, atoms, E_idx32, edge_mask, occ, mask, S, residue_idx, chain_labels, rank, inter):
+    """Edge features, encoder, decoder, head on [B, L] residues whose neighbour ids are local to their row."""
+    dev = atoms.device
+    N = B * L
+    st = stream_ptr()
     hE, _ = _edge_features(pw, atoms, E_idx32, residue_idx, chain_labels, B, L, K, False)
 
     hV = torch.zeros(N, H, device=dev, dtype=torch.float32)
@@ -467,9 +504,7 @@ def _forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_or
         o = pw.occ
         call("mpnn_occupancy_mlp", ptr(occ), ptr(o["w0"]), ptr(o["b0"]), ptr(o["W2"]), ptr(o["b2"]), ptr(o["lnw"]),
              ptr(o["lnb"]), N, ptr(hV), st)
-    if return_intermediates:
-        inter.update(E_idx=E_idx64, D_neighbors=D_nb, edge_mask=edge_mask, occupancy=occ, h_V_enc=[], h_V_dec=[],
-                     h_E_enc=[])
+    if inter is not None:
         inter["h_E0"] = edges_to_natural(hE, N, K).view(B, L, K, H)
 
     gsum = torch.empty(N, H, device=dev, dtype=torch.float32)
@@ -504,25 +539,12 @@ def _forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_or
         call("mpnn_enc_edge_update", ptr(hE), ptr(PQ), PQ.shape[1], 0, H, ptr(E_idx32), ptr(lw["W11b"]),
              ptr(lw["W12"]), ptr(lw["b12"]), ptr(lw["W13"]), ptr(lw["b13"]), ptr(lw["ln3w"]), ptr(lw["ln3b"]), B, L, K,
              st)
-        if return_intermediates:
+        if inter is not None:
             inter["h_V_enc"].append(hV.view(B, L, H))
             inter["h_E_enc"].append(edges_to_natural(hE, N, K).view(B, L, K, H))
 
     # ---- decoder
     if n_dec:
-        chain_M = _f32(chain_M) * mask
-        if fix_order is not None:
-            order = _i64(fix_order)
-        else:
-            # reference :489-491 (random decoding order; the argsort of a [B,L] key is host-side plumbing)
-            order = torch.argsort((chain_M + 0.0001) * torch.abs(torch.randn(chain_M.shape, device=dev)))
-        rank = torch.zeros(N, device=dev, dtype=torch.int32)
-        call("mpnn_order_rank", ptr(order), B, L, ptr(rank), st)
-        if return_intermediates:
-            bw = torch.empty(B, L, K, device=dev, dtype=torch.float32)
-            fw = torch.empty_like(bw)
-            call("mpnn_order_masks", ptr(rank), ptr(E_idx64), ptr(mask), ptr(edge_mask), B, L, K, ptr(bw), ptr(fw), st)
-            inter.update(mask_bw=bw, mask_fw=fw, order=order)
         # projection buffer after the last encoder stage (g_init when there is no encoder):
         #   [P' | Q' |] Pa_0 | A_0 | PVenc_0 | PVenc_1 | ...      (A_l = W1d_l h + W1c_l W_s[S])
         base = 2 * H if n_enc else 0
@@ -541,14 +563,11 @@ def _forward(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, fix_or
             hV = hVn
             if PQn is not None:
                 PQd, offPa, offA = PQn, 0, H
-            if return_intermediates:
+            if inter is not None:
                 inter["h_V_dec"].append(hV.view(B, L, H))
 
     log_probs = torch.empty(B, L, pw.n_letters, device=dev, dtype=torch.float32)
     call("mpnn_logits_log_softmax", ptr(hV), ptr(pw.Wlogit), ptr(pw.blogit), pw.n_letters, N, ptr(log_probs), st)
-    if return_intermediates:
-        inter["log_probs"] = log_probs
-        return inter
     return log_probs
 
 

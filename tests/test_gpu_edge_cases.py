@@ -151,3 +151,4 @@ def test_more_than_48_neighbours(kw, B, L):
         model(*args)                                   # grad mode on: differentiable path
     with pytest.raises(NotImplementedError):
         model.sample(d["X"], d["mask"], d["chain_M"], d["residue_idx"], d["chain_encoding_all"])
+
