@@ -150,3 +150,34 @@ def test_sparse_f16_products_stay_within_the_reduced_precision_bar():
     d = float((low - ref).abs().max())
     assert 0.0 < d <= 5e-2, d
     assert float((low.argmax(-1) == ref.argmax(-1)).float().mean()) >= 0.97
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_sparse_random_configurations(seed):
+    """Random constructor arguments, ragged graphs, unresolved residues and decoding orders against the oracle."""
+    import numpy as np
+
+    from mpnn_amd.sparse import ProteinMPNN
+    from mpnn_amd.synthetic import synthetic_flat_batch
+    from oracle import sparse_oracle as so
+
+    rng = np.random.default_rng(1000 + seed)
+    kw = dict(num_neighbors=int(rng.choice([4, 16, 30, 33, 48, 64])), num_encoder_layers=int(rng.integers(0, 4)),
+              num_decoder_layers=int(rng.integers(0, 4)), use_virtual_center=bool(rng.random() < 0.4))
+    if rng.random() < 0.3:
+        kw["edge_cutoff"] = float(rng.uniform(6.0, 10.0))
+    if rng.random() < 0.3:
+        kw["occupancy_cutoff"] = float(rng.uniform(5.0, 10.0))
+    lengths = [int(v) for v in rng.integers(3, 120, size=int(rng.integers(1, 5)))]
+    bkw = dict(lengths=lengths, seed=int(rng.integers(0, 1 << 20)), n_chains=int(rng.integers(1, 4)),
+               design_fraction=float(rng.uniform(0.2, 1.0)), unresolved_every=int(rng.choice([0, 0, 5, 17])))
+    torch.manual_seed(seed)
+    model = randomized(ProteinMPNN(**kw), seed=seed + 50).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    b = synthetic_flat_batch(**bkw)
+    order = b.pop("decoding_order")
+    with torch.no_grad():
+        ref = so.forward(sd, oracle_cfg(kw), **b, decoding_order=order)
+    out = model.to("cuda")(**{k: v.to("cuda") for k, v in b.items()}, decoding_order=order.to("cuda"))
+    err = (out.cpu().double() - ref.double()).abs()
+    assert bool((err <= 1e-5 + 1e-4 * ref.double().abs()).all()), (kw, bkw, float(err.max()))
