@@ -508,28 +508,30 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
     if model.occupancy_mlp is not None and occ is not None:
         hV = hV + model.occupancy_mlp(occ.view(N, 1))
     enc, dec = list(model.encoder_layers), list(model.decoder_layers)
+    # every [128, 128 n] weight is cut into its column blocks ONCE (torch.split: one autograd node whose backward is a
+    # single cat of the blocks' gradients; slicing block by block costs a zero fill, a copy and an add per use)
+    W1s = {id(lyr): lyr.W1.weight.split(H, dim=1) for lyr in enc + dec}
+    W11s = {id(lyr): lyr.W11.weight.split(H, dim=1) for lyr in enc}
 
     def msg_blocks(lyr):      # P = W1a h + b1, Q = W1c h
-        return [(lyr.W1.weight[:, :H], lyr.W1.bias), (lyr.W1.weight[:, 2 * H:3 * H], None)]
+        return [(W1s[id(lyr)][0], lyr.W1.bias), (W1s[id(lyr)][2], None)]
 
     def dec_first_blocks():   # Pa_0, A_0 (without the sequence term), the encoder rows of every decoder layer
         if not dec:
             return []
-        return ([(dec[0].W1.weight[:, :H], dec[0].W1.bias), (dec[0].W1.weight[:, 3 * H:], None)] +
-                [(d_.W1.weight[:, 3 * H:], None) for d_ in dec])
+        return ([(W1s[id(dec[0])][0], dec[0].W1.bias), (W1s[id(dec[0])][3], None)] +
+                [(W1s[id(d_)][3], None) for d_ in dec])
 
     first = msg_blocks(enc[0]) if enc else dec_first_blocks()
     proj = [linear(hV, W, b) for W, b in first]
     for l, lyr in enumerate(enc):
-        W1, W11 = lyr.W1.weight, lyr.W11.weight
-        gsum, cnt = MessageFn.apply(g, slot, False, hE, proj[0], proj[1], None, W1[:, H:2 * H], lyr.W2.weight,
-                                    lyr.W2.bias)
+        W1, W11 = W1s[id(lyr)], W11s[id(lyr)]
+        gsum, cnt = MessageFn.apply(g, slot, False, hE, proj[0], proj[1], None, W1[1], lyr.W2.weight, lyr.W2.bias)
         nxt = msg_blocks(enc[l + 1]) if l + 1 < len(enc) else dec_first_blocks()
-        hV, proj = _node_update(lyr, hV, gsum, cnt, g.mask, p_drop,
-                                [(W11[:, :H], lyr.W11.bias), (W11[:, 2 * H:3 * H], None)] + nxt)
+        hV, proj = _node_update(lyr, hV, gsum, cnt, g.mask, p_drop, [(W11[0], lyr.W11.bias), (W11[2], None)] + nxt)
         drop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
         out_slot = GradSlot()
-        hE = EdgeUpdateFn.apply(g, slot, out_slot, p_drop, drop_seed, hE, proj[0], proj[1], W11[:, H:2 * H],
+        hE = EdgeUpdateFn.apply(g, slot, out_slot, p_drop, drop_seed, hE, proj[0], proj[1], W11[1],
                                 lyr.W12.weight, lyr.W12.bias, lyr.W13.weight, lyr.W13.bias, lyr.norm3.weight,
                                 lyr.norm3.bias)
         slot = out_slot
@@ -548,10 +550,10 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
         hS = model.W_s(S.reshape(-1))
         Pa, A0, Benc = proj[0], proj[1], proj[2:]
         for l, lyr in enumerate(dec):
-            W1 = lyr.W1.weight
-            A = A0 + linear(hS, W1[:, 2 * H:3 * H])      # sequence term W1c W_s[S] of the decoded neighbours
-            gsum, cnt = MessageFn.apply(g, slot, True, hE, Pa, A, Benc[l], W1[:, H:2 * H], lyr.W2.weight, lyr.W2.bias)
-            nxt = [(dec[l + 1].W1.weight[:, :H], dec[l + 1].W1.bias), (dec[l + 1].W1.weight[:, 3 * H:], None)] \
+            W1 = W1s[id(lyr)]
+            A = A0 + linear(hS, W1[2])      # sequence term W1c W_s[S] of the decoded neighbours
+            gsum, cnt = MessageFn.apply(g, slot, True, hE, Pa, A, Benc[l], W1[1], lyr.W2.weight, lyr.W2.bias)
+            nxt = [(W1s[id(dec[l + 1])][0], dec[l + 1].W1.bias), (W1s[id(dec[l + 1])][3], None)] \
                 if l + 1 < len(dec) else []
             hV, pr = _node_update(lyr, hV, gsum, cnt, g.mask, p_drop, nxt)
             if pr:
