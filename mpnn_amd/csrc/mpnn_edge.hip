@@ -379,8 +379,8 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 
   const float* row[KT];
   setup(node, row);
-  f32x4 x0[2][KT];  // k-step 0 of the residue's hE, always loaded one phase ahead
 #if MPNN_UPD_X0
+  f32x4 x0[2][KT];  // k-step 0 of the residue's hE, loaded one phase ahead
   load_kstep<KT>(hE + (size_t)node * (MPNN_NT * KT * 64) + lane, 0, x0);
 #endif
   f32x4 h2[MPNN_NT][KT];  // carries the next residue's gathered Q' rows across iterations
