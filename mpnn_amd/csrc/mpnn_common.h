@@ -88,7 +88,19 @@ __device__ __forceinline__ float gelu(float x) {
   q = fmaf(q, a, 1.151201725e+00f);
   q = fmaf(q, a, 9.999930859e-01f);
   const float e = __builtin_amdgcn_exp2f(-q);          // Phi(-|x|)
+#ifdef MPNN_GELU_NOASM
   return fmaf(-ax, e, __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()));
+#else
+  // relu(x) - |x| e as exactly two instructions.  Left to hipcc this tail costs four issue slots per element: the
+  // relu becomes a canonicalising v_max pair, and the SLP vectoriser fuses two elements' FMAs into one v_pk_fma_f32,
+  // which has no |x| modifier (one v_or per element to build -|x|) and occupies the issue port ~10 cycles next to
+  // MFMAs (tools/ubench/coissue.hip) against 4.2 for a plain v_fma_f32.  x has already been read by the v_med3 above,
+  // so no MFMA -> VALU wait state is pending on it; the v_max between v_exp and the v_fma covers the one wait state a
+  // transcendental's result needs.
+  float r, o;
+  asm("v_max_f32 %0, 0, %2\n\tv_fma_f32 %1, -|%2|, %3, %0" : "=&v"(r), "=v"(o) : "v"(x), "v"(e));
+  return o;
+#endif
 }
 #endif
 
@@ -134,6 +146,29 @@ __device__ __forceinline__ float column_sum(float v) {
   v = row_ror_add<2>(v);
   v = row_ror_add<1>(v);
   return v;
+}
+
+// the same reduction for the four registers of a tile at once: v_add_f32_dpp (rotation and add in ONE instruction;
+// hipcc keeps v_mov_b32_dpp + a packed add, 1.5 slower-issuing instructions per step).  The four registers are
+// interleaved, so a register is re-read three instructions after it was written (a DPP read needs two wait states
+// behind the VALU write of its source); the leading s_nop covers the producer of the first operand.
+__device__ __forceinline__ f32x4 column_sum4(f32x4 v) {
+#if defined(MPNN_ABL_NOREDUCE)
+  return v;
+#elif defined(MPNN_DPP_NOASM)
+  v.x = column_sum(v.x); v.y = column_sum(v.y); v.z = column_sum(v.z); v.w = column_sum(v.w);
+  return v;
+#else
+  float a = v.x, b = v.y, c = v.z, d = v.w;
+#define MPNN_ROR4(n)                                                                  \
+  "v_add_f32_dpp %0, %0, %0 row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"            \
+  "v_add_f32_dpp %1, %1, %1 row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"            \
+  "v_add_f32_dpp %2, %2, %2 row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"            \
+  "v_add_f32_dpp %3, %3, %3 row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"
+  asm("s_nop 1\n\t" MPNN_ROR4(8) MPNN_ROR4(4) MPNN_ROR4(2) MPNN_ROR4(1) : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef MPNN_ROR4
+  return f32x4{a, b, c, d};
+#endif
 }
 
 // Y[to][c] += Wp[to][ti] * X[ti][c]   for to in [TO0, TO1), ti in [0, NTI)

@@ -161,7 +161,7 @@ __device__ __forceinline__ void reduce_store(f32x4 (&y)[MPNN_NT][KT], const floa
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < KT; ++c) s += gelu4(y[t][c]) * w[c];
-    s.x = column_sum(s.x); s.y = column_sum(s.y); s.z = column_sum(s.z); s.w = column_sum(s.w);
+    s = column_sum4(s);
     if (col == 0) *reinterpret_cast<f32x4*>(out + 16 * t + 4 * g) = s;
     FENCE();
   }
@@ -299,7 +299,9 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
       for (int c = 0; c < KT; ++c) h1[t][c] = row_tile(rown[c], t);
-    reduce_store<KT>(y, w, gsum + (size_t)node * MPNN_H, lane, [&]() { load_kstep<KT>(edge_block(nxt), 0, x0); });
+    STAMP(3);
+    reduce_store<KT>(y, w, gsum + (size_t)node * MPNN_H, lane, [&]() { STAMP(4); load_kstep<KT>(edge_block(nxt), 0, x0); STAMP(5); });
+    STAMP(6);
     if (!DEC) {
       float csum = 0.f;
 #pragma unroll
@@ -312,7 +314,7 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
       s[c] = sn[c];
       w[c] = wn[c];
     }
-    STAMP(3);
+    STAMP(7);
   }
   STAMP_FLUSH(0);
 }
@@ -640,7 +642,7 @@ k_message_tiles(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, in
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
       f32x4 sm = gacc[t][0];
-      sm.x = column_sum(sm.x); sm.y = column_sum(sm.y); sm.z = column_sum(sm.z); sm.w = column_sum(sm.w);
+      sm = column_sum4(sm);
       if (col == 0) *reinterpret_cast<f32x4*>(gout + 16 * t + 4 * g) = sm;
     }
     if (!DEC) {
@@ -718,7 +720,7 @@ k_message_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, in
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
       f32x4 sm = gelu4(y[t][0]) * w;
-      sm.x = column_sum(sm.x); sm.y = column_sum(sm.y); sm.z = column_sum(sm.z); sm.w = column_sum(sm.w);
+      sm = column_sum4(sm);
       if (col == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) unsafeAtomicAdd(gout + 16 * t + r, sm[r]);
@@ -844,7 +846,7 @@ level_message(const LevelItem& it, const h8* W1s, const h8* W2s, const float* __
 #pragma unroll
   for (int t = 0; t < MPNN_NT; ++t) {
     f32x4 sm = gelu4(y[t][0]) * it.w;
-    sm.x = column_sum(sm.x); sm.y = column_sum(sm.y); sm.z = column_sum(sm.z); sm.w = column_sum(sm.w);
+    sm = column_sum4(sm);
     if (col == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) atomicAdd(&gsl[it.nl][16 * t + 4 * g + r], sm[r]);
@@ -1144,7 +1146,7 @@ extern "C" int MPNN_API(mpnn_enc_message)(const float* hE_frag, const float* PQ,
                  "mpnn_enc_message: bad sizes (strides/offsets must be multiples of 4 floats)");
   const int N = B * L, KT = (K + 15) / 16;
 #ifdef MPNN_STAMP
-  stamp_report("message: layer1 | gelu1+split | layer2 | gelu2+reduce+next rows | .. | loop top", 0);
+  stamp_report("message: layer1 | gelu1+split | layer2 | row gathers issue | reduce t<4 | x0 issue | reduce t>=4 | cnt+loop top", 0);
 #endif
   if (MPNN_MSG_TILEWISE || KT > 3) {
     dim3 grid(edge_grid(N, MPNN_MSGT_WAVES)), block(MPNN_MSGT_WAVES * 64);

@@ -33,7 +33,7 @@ __device__ __forceinline__ void first_layer_grad(f32x4 (&y)[MPNN_NT][KT], float 
       if (SCALE) y[t][c] *= s[c];
       __builtin_nontemporal_store(y[t][c], reinterpret_cast<f32x4*>(nat + (size_t)(16 * c + col) * MPNN_H + 16 * t + 4 * g));
     }
-    ps.x = column_sum(ps.x); ps.y = column_sum(ps.y); ps.z = column_sum(ps.z); ps.w = column_sum(ps.w);
+    ps = column_sum4(ps);
     if (col == 0) *reinterpret_cast<f32x4*>(dP + 16 * t + 4 * g) = ps;
     FENCE();
   }

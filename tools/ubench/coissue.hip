@@ -14,6 +14,8 @@ template <int M, int N, int ROLE, int TRANS>
 __global__ void k(float* out, long long* cyc, int iters) {
   f32x4 acc[8];
   float a[16];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 pa[16];
   h8 ha, hb;
 #pragma unroll
   for (int i = 0; i < 8; ++i) { ha[i] = (_Float16)(0.001f * (threadIdx.x + i)); hb[i] = (_Float16)(0.002f * (i + 1)); }
@@ -21,6 +23,9 @@ __global__ void k(float* out, long long* cyc, int iters) {
   for (int i = 0; i < 8; ++i) acc[i] = f32x4{0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < 16; ++i) a[i] = 0.001f * (threadIdx.x + i);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) pa[i] = f32x2{0.001f * (threadIdx.x + i), 0.002f * i};
+  const f32x2 pc1 = f32x2{1.0001f, 1.0002f}, pc2 = f32x2{0.5f, 0.25f};
   const int wave = threadIdx.x >> 6;
   const bool do_m = ROLE == 0, do_v = true;  // ROLE 2: VALU only
   __syncthreads();
@@ -37,7 +42,10 @@ __global__ void k(float* out, long long* cyc, int iters) {
 #pragma unroll
               for (int v = 0; v < N / M; ++v) {
                 const int q = (m * (N / M) + v + rep * 5) & 15;
-                if (TRANS) asm volatile("v_exp_f32 %0, %0" : "+v"(a[q]));
+                if (TRANS == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(a[q]));
+                else if (TRANS == 2) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pa[q]) : "v"(pc1), "v"(pc2));
+                else if (TRANS == 3) asm volatile("v_fmaak_f32 %0, %0, %1, 0x3f7fff8c" : "+v"(a[q]) : "v"(1.0001f));
+                else if (TRANS == 4) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[0]) : "v"(1.0001f), "v"(0.5f));
                 else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[q]) : "v"(1.0001f), "v"(0.5f));
               }
             }
@@ -49,7 +57,10 @@ __global__ void k(float* out, long long* cyc, int iters) {
 #pragma unroll
           for (int v = 0; v < N; ++v) {
             const int q = (v + rep * 5) & 15;
-            if (TRANS) asm volatile("v_exp_f32 %0, %0" : "+v"(a[q]));
+            if (TRANS == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(a[q]));
+            else if (TRANS == 2) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pa[q]) : "v"(pc1), "v"(pc2));
+            else if (TRANS == 3) asm volatile("v_fmaak_f32 %0, %0, %1, 0x3f7fff8c" : "+v"(a[q]) : "v"(1.0001f));
+            else if (TRANS == 4) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[0]) : "v"(1.0001f), "v"(0.5f));
             else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[q]) : "v"(1.0001f), "v"(0.5f));
           }
         }
@@ -59,7 +70,7 @@ __global__ void k(float* out, long long* cyc, int iters) {
   const long long t1 = __builtin_amdgcn_s_memtime();
   float s = 0;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s += a[i];
+  for (int i = 0; i < 16; ++i) s += a[i] + pa[i].x + pa[i].y;
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += acc[i].x + acc[i].y;
   if (s == 12345.678f) out[threadIdx.x] = s;
@@ -123,5 +134,23 @@ int main() {
   run<16, 64, 0, 0>(4, "16 MFMA then 64 fma (4 per MFMA), clustered");
   run<1, 1, 0, 1>(1, "1 MFMA + 1 exp, interleaved");
   run<1, 2, 0, 1>(1, "1 MFMA + 2 exp, interleaved");
+  if (getenv("COISSUE_MORE")) {
+    run<1, 2, 0, 2>(1, "1 MFMA + 2 pk_fma, interleaved");
+    run<1, 4, 0, 2>(1, "1 MFMA + 4 pk_fma, interleaved");
+    run<1, 6, 0, 2>(1, "1 MFMA + 6 pk_fma, interleaved");
+    run<1, 4, 0, 2>(2, "1 MFMA + 4 pk_fma, interleaved");
+    run<16, 64, 0, 2>(2, "16 MFMA then 64 pk_fma (4 per MFMA), clustered");
+    run<1, 4, 2, 2>(1, "VALU only: 4 pk_fma per slot");
+    run<1, 4, 2, 2>(2, "VALU only: 4 pk_fma per slot");
+    run<1, 4, 2, 2>(4, "VALU only: 4 pk_fma per slot");
+    run<1, 4, 0, 3>(1, "1 MFMA + 4 fmaak (literal), interleaved");
+    run<1, 6, 0, 3>(1, "1 MFMA + 6 fmaak (literal), interleaved");
+    run<1, 4, 0, 3>(2, "1 MFMA + 4 fmaak (literal), interleaved");
+    run<1, 4, 2, 3>(2, "VALU only: 4 fmaak per slot");
+    run<1, 4, 0, 4>(1, "1 MFMA + 4 dependent fma, interleaved");
+    run<1, 4, 0, 4>(2, "1 MFMA + 4 dependent fma, interleaved");
+    run<1, 4, 2, 4>(1, "VALU only: 4 dependent fma per slot");
+    run<1, 4, 2, 4>(2, "VALU only: 4 dependent fma per slot");
+  }
   return 0;
 }
