@@ -299,6 +299,28 @@ __device__ __forceinline__ void split_kstep(WPtr Wp, int kk, int lane, const BFr
   }
 }
 
+// one k-step with a hook at the top of every output tile (pinned there by a scheduling fence): loads the caller wants
+// spread over the k-step instead of issued as one burst
+template <int KT, int NKK, int NTO, typename WPtr, typename Hook>
+__device__ __forceinline__ void split_kstep_hook(WPtr Wp, int kk, int lane, const BFrag (&B)[KT], f32x4 (&Y)[NTO][KT],
+                                                 Hook hook) {
+#pragma unroll
+  for (int to = 0; to < NTO; ++to) {
+    hook(to);
+    const h8 a_hi = Wp[((to * NKK + kk) * 2 + 0) * 64 + lane];
+#ifndef MPNN_FAST
+    const h8 a_lo = Wp[((to * NKK + kk) * 2 + 1) * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) Y[to][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, B[c].hi, Y[to][c], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < KT; ++c) Y[to][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, B[c].lo, Y[to][c], 0, 0, 0);
+#endif
+#pragma unroll
+    for (int c = 0; c < KT; ++c) Y[to][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, B[c].hi, Y[to][c], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // Y[to][c] += W[to][:] * X   with X given as NKK k-steps of B fragments
 template <int KT, int NKK, int TO0, int TO1, typename WPtr>
 __device__ __forceinline__ void split_gemm(WPtr Wp, int lane, const BFrag (&B)[NKK][KT], f32x4 (&Y)[TO1 - TO0][KT]) {

@@ -62,6 +62,14 @@ MPNN_KERNELS_BEGIN
 #ifndef MPNN_UPD_WAVES
 #define MPNN_UPD_WAVES 8
 #endif
+// 1: the message kernel issues the next residue's 24 row gathers and its first hE k-step as two bursts (round-2 form);
+// 0: spread over the row tiles of the reduction
+#ifndef MPNN_MSG_BURST
+#define MPNN_MSG_BURST 0
+#endif
+#ifndef MPNN_L1_PIN
+#define MPNN_L1_PIN 2
+#endif
 // tuning switches of the edge update's epilogue (A/B builds): where the next residue's first hE k-step (X0) and its
 // gathered rows (ROWS) are issued.  X0: 0 = at the loop top, 1 = after the LayerNorm statistics (before the stores).
 // ROWS: 0 = right after layer 3, 1 = after the LayerNorm statistics.
@@ -81,7 +89,21 @@ MPNN_KERNELS_BEGIN
 #define MPNN_UPD_X0 0
 #endif
 #ifndef MPNN_UPD_ROWS
-#define MPNN_UPD_ROWS 1
+#define MPNN_UPD_ROWS 2
+#endif
+#ifndef MPNN_UPD_RES_SPREAD
+#define MPNN_UPD_RES_SPREAD 1
+#endif
+// layer 1 touches every cache line of its residue's later hE k-steps with one-dword loads at its start (no registers
+// held: a software prefetch into L2), so the real loads a k-step later find the lines on their way
+#ifndef MPNN_X0_FIRST
+#define MPNN_X0_FIRST 2
+#endif
+#ifndef MPNN_X0_SPAN
+#define MPNN_X0_SPAN 2
+#endif
+#ifndef MPNN_X_PREFETCH
+#define MPNN_X_PREFETCH 0
 #endif
 #ifndef MPNN_UPD_RING
 #define MPNN_UPD_RING 7  // W13 lo fragments in flight ahead of their MFMAs (edge update, layer 3)
@@ -105,9 +127,14 @@ __device__ __forceinline__ void load_kstep(const f32x4* __restrict__ x, int kk, 
 // x0: the tiles of k-step 0, loaded by the caller (persistent kernels issue them one phase early, before the previous
 // residue's epilogue: a wave's vector-memory operations complete in issue order, so a load issued behind the epilogue's
 // stores and gathers would wait for all of them)
-template <int KT>
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// last: called at the top of the LAST k-step, when the other k-step buffer is dead: room for loads whose results are
+// needed right after layer 1 (the residue's own P row) without holding their registers through the whole layer
+template <int KT, typename Hook = NoHook>
 __device__ __forceinline__ void layer1_stream(const h8* Ws, const f32x4* __restrict__ x, int lane,
-                                              f32x4 (&acc)[MPNN_NT][KT], const f32x4 (&x0)[2][KT]) {
+                                              f32x4 (&acc)[MPNN_NT][KT], const f32x4 (&x0)[2][KT], Hook last = Hook()) {
   f32x4 xb[2][2][KT];
 #pragma unroll
   for (int u = 0; u < 2; ++u)
@@ -117,9 +144,41 @@ __device__ __forceinline__ void layer1_stream(const h8* Ws, const f32x4* __restr
   WRing<MPNN_LDS_RING> ring;
   wring_prologue<NKK, MPNN_NT, MPNN_LDS_RING>(ring, Ws + lane);
 #endif
+#if MPNN_X_PREFETCH
+  constexpr int PF_LINES = (MPNN_NT - 2) * KT * 8;  // 128-byte lines of k-steps 1 .. NKK-1 (a tile row is 1 KiB)
+  constexpr int PF_N = (PF_LINES + 63) / 64;
+  float pf[PF_N];
+  {
+    const float* base = reinterpret_cast<const float*>(x - lane) + 2 * KT * 256;
+#pragma unroll
+    for (int i = 0; i < PF_N; ++i) {
+      const int line = 64 * i + lane;
+      pf[i] = 0.f;
+      if (line < PF_LINES) pf[i] = __builtin_nontemporal_load(base + line * 32);
+    }
+  }
+  FENCE();
+#endif
 #pragma unroll
   for (int kk = 0; kk < NKK; ++kk) {
+#if MPNN_L1_PIN == 2
+    // the next k-step's 2 KT tiles, one load per output tile of this k-step (pinned: hipcc otherwise places them all
+    // near the END of the k-step, a few MFMAs before the next k-step waits for them)
+    if (kk + 1 == NKK) last();
+    BFrag b[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) split_pair(xb[kk & 1][0][c], xb[kk & 1][1][c], b[c]);
+    FENCE();
+    split_kstep_hook<KT, NKK, MPNN_NT>(Ws, kk, lane, b, acc, [&](int to) {
+      if (kk + 1 < NKK && to < 2 * KT) xb[(kk + 1) & 1][to / KT][to % KT] = x[((2 * (kk + 1) + to / KT) * KT + to % KT) * 64];
+    });
+#else
     if (kk + 1 < NKK) load_kstep<KT>(x, kk + 1, xb[(kk + 1) & 1]);
+    else last();
+#if MPNN_L1_PIN
+    FENCE();  // hipcc otherwise sinks these loads to the END of the k-step (fewer live registers), a few MFMAs before
+              // the next k-step waits for them
+#endif
     BFrag b[KT];
 #pragma unroll
     for (int c = 0; c < KT; ++c) split_pair(xb[kk & 1][0][c], xb[kk & 1][1][c], b[c]);
@@ -128,8 +187,13 @@ __device__ __forceinline__ void layer1_stream(const h8* Ws, const f32x4* __restr
 #else
     split_kstep<KT, NKK, 0, MPNN_NT>(Ws, kk, lane, b, acc);
 #endif
+#endif
     FENCE();
   }
+#if MPNN_X_PREFETCH
+#pragma unroll
+  for (int i = 0; i < PF_N; ++i) asm volatile("" ::"v"(pf[i]));
+#endif
 }
 
 // Y += W X with W's fragments in LDS, read MPNN_LDS_RING steps ahead
@@ -142,12 +206,12 @@ __device__ __forceinline__ void lds_gemm(const h8* Ws, int lane, const BFrag (&B
 #endif
 }
 
-template <int KT>
+template <int KT, typename Hook = NoHook>
 __device__ __forceinline__ void layer1_stream(const h8* Ws, const f32x4* __restrict__ x, int lane,
-                                              f32x4 (&acc)[MPNN_NT][KT]) {
+                                              f32x4 (&acc)[MPNN_NT][KT], Hook last = Hook()) {
   f32x4 x0[2][KT];
   load_kstep<KT>(x, 0, x0);
-  layer1_stream<KT>(Ws, x, lane, acc, x0);
+  layer1_stream<KT>(Ws, x, lane, acc, x0, last);
 }
 
 // masked neighbour sum of gelu(y) over the residue's edges -> gsum
@@ -157,7 +221,7 @@ __device__ __forceinline__ void reduce_store(f32x4 (&y)[MPNN_NT][KT], const floa
   const int g = lane >> 4, col = lane & 15;
 #pragma unroll
   for (int t = 0; t < MPNN_NT; ++t) {
-    if (t == MPNN_NT / 2) midway();  // half of y is dead: room for the next residue's first loads
+    midway(t);  // the next residue's loads, a few per row tile (y[0 .. t) is dead: registers for them)
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < KT; ++c) s += gelu4(y[t][c]) * w[c];
@@ -214,7 +278,10 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
       const int e = 16 * c + col;
-      const int jl = E_idx[(size_t)sh * Kp + e];
+      int jl = E_idx[(size_t)sh * Kp + e];
+#ifdef MPNN_ABL_ROWSAME  // timing-only ablation build (never shipped): all 16 columns gather the residue's own row
+      jl = nd - b * L;
+#endif
       const int jn = b * L + jl;
       float em = 1.0f;
       if (edge_mask && e < K) em = edge_mask[(size_t)sh * K + e];
@@ -241,7 +308,10 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 #pragma unroll
     for (int c = 0; c < KT; ++c) h1[t][c] = row_tile(row[c], t);
   auto edge_block = [&](int nd) {  // a residue's hE block (shared-structure decoding reads it at residue % enc_mod)
-    const int ne = (DEC && nd >= enc_mod) ? nd % enc_mod : nd;
+    int ne = (DEC && nd >= enc_mod) ? nd % enc_mod : nd;
+#ifdef MPNN_ABL_XSAME  // timing-only ablation build (never shipped): every hE read hits L2 (64 residues' blocks)
+    ne &= 63;
+#endif
     return hE + (size_t)ne * (MPNN_NT * KT * 64) + lane;
   };
   f32x4 x0[2][KT];  // k-step 0 of the residue's hE, always loaded one phase ahead
@@ -251,13 +321,12 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
   for (; node < Nend; node += stride) {
     const int nxt = (node + stride < Nend) ? node + stride : Nend - 1;  // tail: harmless re-load of a valid residue
     STAMP(7);
-    f32x4 p[MPNN_NT];  // P_i: needed only after layer 1
-    {
-      const float* Pi = Pbuf + (size_t)node * ldp + offP + 4 * g;
+    f32x4 p[MPNN_NT];  // P_i: needed only after layer 1, loaded during its last k-step
+    const float* Pi = Pbuf + (size_t)node * ldp + offP + 4 * g;
+    layer1_stream<KT>(W1s, edge_block(node), lane, h1, x0, [&]() {
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t) p[t] = row_tile(Pi, t);
-    }
-    layer1_stream<KT>(W1s, edge_block(node), lane, h1, x0);
+    });
     STAMP(0);
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
@@ -293,14 +362,39 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 #pragma unroll
         for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(y[t][c], &o[(t * KT + c) * 64]);
     }
-    // h1 is free: gather the next residue's rows under the GELU + reduction below; its first hE k-step follows once
-    // half of y has been reduced (registers)
+    // h1 is free: the next residue's gathered rows and its first hE k-step are issued a few loads per row tile of the
+    // GELU + reduction below, not as one burst: 30 back-to-back loads (16 rows each) fill the address unit's queue and
+    // the wave then waits at the ISSUE of the later ones (measured with MPNN_STAMP: 12 % of the kernel); the k-step
+    // starts once half of y has been reduced (registers)
+#if MPNN_MSG_BURST
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
       for (int c = 0; c < KT; ++c) h1[t][c] = row_tile(rown[c], t);
+#endif
     STAMP(3);
-    reduce_store<KT>(y, w, gsum + (size_t)node * MPNN_H, lane, [&]() { STAMP(4); load_kstep<KT>(edge_block(nxt), 0, x0); STAMP(5); });
+    reduce_store<KT>(y, w, gsum + (size_t)node * MPNN_H, lane, [&](int t) {
+#if MPNN_MSG_BURST
+      if (t == MPNN_NT / 2) load_kstep<KT>(edge_block(nxt), 0, x0);
+#else
+#pragma unroll
+      for (int c = 0; c < KT; ++c) h1[t][c] = row_tile(rown[c], t);
+      // the k-step's 2 KT tiles over MPNN_X0_SPAN row tiles from MPNN_X0_FIRST on (a dead y tile frees half a k-step
+      // tile pair; loads complete in issue order and the k-step is what layer 1 needs FIRST, so it goes out early)
+      if (t >= MPNN_X0_FIRST && t < MPNN_X0_FIRST + MPNN_X0_SPAN) {
+        const f32x4* xn = edge_block(nxt);
+#pragma unroll
+        for (int i = 0; i < 2 * KT; ++i)
+          if (i * MPNN_X0_SPAN / (2 * KT) == t - MPNN_X0_FIRST) {
+#ifdef MPNN_ABL_NOXLOAD
+            x0[i / KT][i % KT] = f32x4{1.f, 2.f, 3.f, 4.f};
+#else
+            x0[i / KT][i % KT] = xn[i * 64];
+#endif
+          }
+      }
+#endif
+    });
     STAMP(6);
     if (!DEC) {
       float csum = 0.f;
@@ -399,21 +493,21 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
     LAUNDER(W3u);
     const h8* W3g = W3u + lane;
     f32x4* x = hE + (size_t)node * (MPNN_NT * KT * 64) + lane;
-    f32x4 p[MPNN_NT];
-    {
-      const float* Pi = Pb + (size_t)node * ldp + offP + 4 * g;
+    f32x4 p[MPNN_NT];  // P'_i: needed only after layer 1, loaded during its last k-step
+    const float* Pi = Pb + (size_t)node * ldp + offP + 4 * g;
+    auto load_p = [&]() {
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t) p[t] = row_tile(Pi, t);
-    }
+    };
     f32x4 h1[MPNN_NT][KT];
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
       for (int c = 0; c < KT; ++c) h1[t][c] = h2[t][c];
 #if MPNN_UPD_X0
-    layer1_stream<KT>(W1s, x, lane, h1, x0);
+    layer1_stream<KT>(W1s, x, lane, h1, x0, load_p);
 #else
-    layer1_stream<KT>(W1s, x, lane, h1);
+    layer1_stream<KT>(W1s, x, lane, h1, load_p);
 #endif
     STAMP(0);
 #pragma unroll
@@ -464,6 +558,25 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #endif
     // residual e -> layer 3's initial accumulator (loads fly under the GELU + split of h2); the training form
     // adds it after the dropout of the MLP output instead
+#if MPNN_UPD_RES_SPREAD  // six residual loads per k-step of the GELU + split loop instead of one burst of 24
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+          const int t = 2 * kk + u;
+#ifdef MPNN_ABL_NORES
+          h1[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
+          h1[t][c] = SAVE ? f32x4{0.f, 0.f, 0.f, 0.f} : x[(t * KT + c) * 64];
+#endif
+        }
+#pragma unroll
+      for (int c = 0; c < KT; ++c) split_pair(gelu4(h2[2 * kk][c]), gelu4(h2[2 * kk + 1][c]), hb[kk][c]);
+      FENCE();
+    }
+#else
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
@@ -473,6 +586,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
       for (int c = 0; c < KT; ++c) h1[t][c] = SAVE ? f32x4{0.f, 0.f, 0.f, 0.f} : x[(t * KT + c) * 64];
 #endif
     tile_to_bfrag<MPNN_NT, KT, true>(h2, hb);
+#endif
     STAMP(3);
     // ---- layer 3.  step q = kk * 8 + to
 #ifdef MPNN_ABL_W3LDS  // timing-only ablation build: never shipped
@@ -503,6 +617,13 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #endif
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
+#if MPNN_UPD_ROWS == 2  // a few gathers per row tile instead of one burst of 24 (see the message kernel)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) h2[t][c] = row_tile(rown[c], t);
+#if MPNN_UPD_X0
+      if (t < 2 * KT) x0[t / KT][t % KT] = hE[(size_t)nxt * (MPNN_NT * KT * 64) + lane + t * 64];
+#endif
+#endif
       const f32x4 bb = *reinterpret_cast<const f32x4*>(b13s + 16 * t + 4 * g);
 #pragma unroll
       for (int c = 0; c < KT; ++c) {
@@ -514,15 +635,18 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
           __builtin_nontemporal_store(h1[t][c], &svz[soff + (t * KT + c) * 64]);
         }
       }
+#if MPNN_UPD_ROWS == 2
+      FENCE();
+#endif
     }
     // LayerNorm statistics; then the next residue's first hE k-step is issued - BEFORE this residue's stores (vector
     // memory operations complete in issue order) - and the tiles are normalised and stored one by one
     float mean[KT], rstd[KT];
     tile_layernorm_stats<KT>(h1, mean, rstd);
-#if MPNN_UPD_X0
+#if MPNN_UPD_X0 && MPNN_UPD_ROWS != 2
     load_kstep<KT>(hE + (size_t)nxt * (MPNN_NT * KT * 64) + lane, 0, x0);
 #endif
-#if MPNN_UPD_ROWS
+#if MPNN_UPD_ROWS == 1
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
@@ -1146,7 +1270,7 @@ extern "C" int MPNN_API(mpnn_enc_message)(const float* hE_frag, const float* PQ,
                  "mpnn_enc_message: bad sizes (strides/offsets must be multiples of 4 floats)");
   const int N = B * L, KT = (K + 15) / 16;
 #ifdef MPNN_STAMP
-  stamp_report("message: layer1 | gelu1+split | layer2 | row gathers issue | reduce t<4 | x0 issue | reduce t>=4 | cnt+loop top", 0);
+  stamp_report("message: layer1 | gelu1+split | layer2 | save | - | - | reduce + next loads | cnt+loop top", 0);
 #endif
   if (MPNN_MSG_TILEWISE || KT > 3) {
     dim3 grid(edge_grid(N, MPNN_MSGT_WAVES)), block(MPNN_MSGT_WAVES * 64);
