@@ -88,6 +88,9 @@ MPNN_KERNELS_BEGIN
 #ifndef MPNN_UPD_X0
 #define MPNN_UPD_X0 0
 #endif
+#ifndef MPNN_UPD_X0_T
+#define MPNN_UPD_X0_T 2
+#endif
 #ifndef MPNN_UPD_ROWS
 #define MPNN_UPD_ROWS 2
 #endif
@@ -620,7 +623,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #if MPNN_UPD_ROWS == 2  // a few gathers per row tile instead of one burst of 24 (see the message kernel)
 #pragma unroll
       for (int c = 0; c < KT; ++c) h2[t][c] = row_tile(rown[c], t);
-#if MPNN_UPD_X0
+#if MPNN_UPD_X0 == 1
       if (t < 2 * KT) x0[t / KT][t % KT] = hE[(size_t)nxt * (MPNN_NT * KT * 64) + lane + t * 64];
 #endif
 #endif
@@ -643,7 +646,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
     // memory operations complete in issue order) - and the tiles are normalised and stored one by one
     float mean[KT], rstd[KT];
     tile_layernorm_stats<KT>(h1, mean, rstd);
-#if MPNN_UPD_X0 && MPNN_UPD_ROWS != 2
+#if MPNN_UPD_X0 == 1 && MPNN_UPD_ROWS != 2
     load_kstep<KT>(hE + (size_t)nxt * (MPNN_NT * KT * 64) + lane, 0, x0);
 #endif
 #if MPNN_UPD_ROWS == 1
@@ -666,6 +669,17 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #endif
 #pragma unroll
       for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(h1[t][c], &xo[(t * KT + c) * 64]);
+#if MPNN_UPD_X0 == 2
+      // the next residue's first hE k-step, half of it behind each of two stored row tiles (MPNN_UPD_X0_T, + 1): the
+      // stored tiles' registers are free, so the k-step costs no extra registers, and layer 1 does not start with a
+      // whole HBM round trip
+      if (t == MPNN_UPD_X0_T || t == MPNN_UPD_X0_T + 1) {
+        const f32x4* xn = hE + (size_t)nxt * (MPNN_NT * KT * 64) + lane;
+#pragma unroll
+        for (int c = 0; c < KT; ++c) x0[t - MPNN_UPD_X0_T][c] = xn[((t - MPNN_UPD_X0_T) * KT + c) * 64];
+      }
+      FENCE();
+#endif
     }
     STAMP(5);
   }
