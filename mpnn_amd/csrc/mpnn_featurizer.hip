@@ -1,9 +1,23 @@
 // Backbone featurizer kernels for gfx950 (reference: src/mpnn/models/model_utils.py
 // ProteinFeatures, :180-360).  Built with -ffp-contract=off: the neighbour search must
 // round every operation exactly like the reference's separate ATen ops do.
-#include "mpnn_common.h"
+#include "mpnn_edge_common.h"
 
 MPNN_KERNELS_BEGIN
+
+// Distance of an atom pair for the RBF features: the hardware square root (v_sqrt_f32, 1 ulp).  The neighbour SEARCH
+// needs the correctly rounded sqrtf (its ranks must equal the reference's bit for bit) and keeps it; here the distance
+// only enters exp(-((d - mu) / 1.25)^2), where 1 ulp of d (1e-6 A at 20 A) moves a feature by < 2e-6 relative, and
+// sqrtf's software refinement (cmp / cndmask / fma: ~20 instructions, 75 roots per residue) was 45 % of the
+// featurizer's vector instructions.
+__device__ __forceinline__ float rbf_distance(float d2) {
+#ifdef MPNN_RBF_EXACT_SQRT
+  return sqrtf(d2);
+#else
+  return __builtin_amdgcn_sqrtf(d2);
+#endif
+}
+
 
 // ---------------------------------------------------------------------------
 // backbone atoms: X [N,4,3] (+noise) -> atoms [N][6][4] = N, CA, C, O, CB, V (xyz + pad)
@@ -290,6 +304,12 @@ __global__ void k_pos_table(const float* __restrict__ W, const float* __restrict
 #ifndef MPNN_FEAT_RING
 #define MPNN_FEAT_RING 4  // weight fragments in flight ahead of their MFMAs
 #endif
+#ifndef MPNN_FEAT_STAGGER
+#define MPNN_FEAT_STAGGER 1
+#endif
+#ifndef MPNN_FEAT_PERSISTENT
+#define MPNN_FEAT_PERSISTENT 1  // K <= 48: k_edge_features_ring (weights through LDS, once per eight residues)
+#endif
 template <int KT, int A, bool SAVE>
 __global__ void __launch_bounds__(256, 2)
 k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, const long long* __restrict__ residue_idx,
@@ -334,7 +354,7 @@ k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, 
     for (int c = 0; c < KT; ++c) {
       const f32x4 Bj = reinterpret_cast<const f32x4*>(atoms + (size_t)jn[c] * 24)[pair % A];
       const float dx = Ai.x - Bj.x, dy = Ai.y - Bj.y, dz = Ai.z - Bj.z;
-      const float d = sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
+      const float d = rbf_distance(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float z = (d - mu[r]) * 0.96089792702915982f;  // (1 / 1.25) sqrt(log2 e)
@@ -422,6 +442,208 @@ k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, 
   for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
     for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(acc[t][c], &out[(t * KT + c) * 64 + lane]);
+}
+
+// ---------------------------------------------------------------------------
+// edge features, persistent form (K <= 48): the same arithmetic in the same order as k_edge_features (results are
+// bit-identical), but the weights no longer stream from L2 once per RESIDUE (272 KiB per wave: 4.4 GB of L2 reads per
+// B32 x L512 launch, the kernel's bound) - a workgroup of eight waves walks its residues eight at a time, all waves on
+// the same k-step, and each 16 KiB k-step image of W_emb (8 output tiles x hi/lo) is brought into a three-slot LDS
+// ring ONCE per round by LDS-DMA, two k-steps ahead of its MFMAs; W_e (64 KiB) stays resident in LDS.  One barrier
+// per k-step: it tells every wave that the slot's image has landed (each wave waits for its own DMA pieces first) and
+// that the slot refilled next is no longer being read.  The neighbours' atoms are gathered once per residue into
+// registers (the streaming form re-reads them for every atom pair).
+// ---------------------------------------------------------------------------
+constexpr int FEAT_RING_SLOTS = 3;
+constexpr int FEAT_KSTEP_H8 = MPNN_NT * 2 * 64;  // h8 elements of one k-step image (16 KiB)
+constexpr int FEAT_WAVES = 8;
+
+template <int KT, int A, bool SAVE>
+__global__ void __launch_bounds__(FEAT_WAVES * 64)
+k_edge_features_ring(const float* __restrict__ atoms, const int* __restrict__ E_idx,
+                     const long long* __restrict__ residue_idx, const long long* __restrict__ chain_labels,
+                     const float* __restrict__ pos_table, const float* __restrict__ rbf_mu,
+                     const h8* __restrict__ Wemb, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                     const h8* __restrict__ We, const float* __restrict__ be, int N, int L, int K,
+                     float* __restrict__ E_nat, float* __restrict__ hE, f32x4* __restrict__ E0_frag,
+                     f32x4* __restrict__ E_frag, const float* __restrict__ emb_bias) {
+  constexpr int NT_IN = A * A + 1;
+  constexpr int NKK_IN = (NT_IN + 1) / 2;
+  constexpr int R = FEAT_RING_SLOTS;
+  __shared__ h8 ring[R * FEAT_KSTEP_H8];
+  __shared__ h8 wes[WSPLIT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  constexpr int Kp = KT * 16;
+
+  // rounds of this workgroup: every wave runs all of them (barriers), a wave without a residue in the last round
+  // recomputes its previous one and stores nothing
+  const ResidueRange rr = residue_range(N, FEAT_WAVES, wave);
+  const ResidueRange r0 = residue_range(N, FEAT_WAVES, 0);
+  const int n_rounds = r0.first < r0.end ? (r0.end - r0.first + r0.stride - 1) / r0.stride : 0;
+  if (n_rounds == 0) return;
+  const int n_steps = n_rounds * NKK_IN;
+
+  // k-step image s (flattened over rounds) -> ring slot s % R: 16 pieces of 1 KiB (output tile, hi / lo), two per wave
+  auto fill = [&](int s_) {
+    const int kk = s_ % NKK_IN;
+    h8* slot = ring + (s_ % R) * FEAT_KSTEP_H8;
+#pragma unroll
+    for (int i = 0; i < 2 * MPNN_NT / FEAT_WAVES; ++i) {
+      const int piece = i * FEAT_WAVES + wave, to = piece >> 1, part = piece & 1;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(Wemb + ((to * NKK_IN + kk) * 2 + part) * 64 + lane),
+          (__attribute__((address_space(3))) void*)(slot + piece * 64), 16, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int s_ = 0; s_ < R - 1; ++s_)
+    if (s_ < n_steps) fill(s_);
+  lds_fill(wes, We, WSPLIT);
+
+  float mu[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) mu[r] = rbf_mu[4 * g + r];
+
+  int step = 0;
+  for (int round = 0; round < n_rounds; ++round) {
+    int node = rr.first + round * rr.stride;
+    const bool has = node < rr.end;
+    if (!has) node = rr.first < rr.end ? rr.end - 1 - ((rr.end - 1 - rr.first) % rr.stride) : (N - 1);
+    node = __builtin_amdgcn_readfirstlane(node);  // wave-uniform: the residue's own atoms come through scalar loads
+    const int b = node / L;
+    int jn[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) jn[c] = b * L + E_idx[(size_t)node * Kp + 16 * c + col];
+    // this residue's atoms and its neighbours' (A x KT gathers, once)
+    f32x4 Ai[A];
+    float Bj[A][KT][3];
+    {
+      const f32x4* atom_i = reinterpret_cast<const f32x4*>(atoms + (size_t)node * 24);
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        Ai[a] = atom_i[a];
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+          const f32x4 q = reinterpret_cast<const f32x4*>(atoms + (size_t)jn[c] * 24)[a];
+          Bj[a][c][0] = q.x; Bj[a][c][1] = q.y; Bj[a][c][2] = q.z;
+        }
+      }
+    }
+    f32x4 acc[MPNN_NT][KT];
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (emb_bias) b0 = *reinterpret_cast<const f32x4*>(emb_bias + 16 * t + 4 * g);
+#pragma unroll
+      for (int c = 0; c < KT; ++c) acc[t][c] = b0;
+    }
+    auto feature_tile = [&](int tt, f32x4 (&x)[KT]) {
+      if (tt < A * A) {
+        const f32x4 P = Ai[tt / A];
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+          const float dx = P.x - Bj[tt % A][c][0], dy = P.y - Bj[tt % A][c][1], dz = P.z - Bj[tt % A][c][2];
+          const float d = rbf_distance(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float z = (d - mu[r]) * 0.96089792702915982f;  // (1 / 1.25) sqrt(log2 e)
+            x[c][r] = __builtin_amdgcn_exp2f(-(z * z));           // exp(-((d - mu) / 1.25)^2)
+          }
+        }
+      } else if (tt == A * A) {
+        const long long ri = residue_idx[node], ci = chain_labels[node];
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+          const long long off = ri - residue_idx[jn[c]];
+          const bool same = (ci - chain_labels[jn[c]]) == 0;
+          long long d = off + 32;
+          d = d < 0 ? 0 : (d > 64 ? 64 : d);
+          if (!same) d = 65;
+          x[c] = *reinterpret_cast<const f32x4*>(pos_table + d * 16 + 4 * g);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < KT; ++c) x[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+#pragma unroll
+    for (int kk = 0; kk < NKK_IN; ++kk, ++step) {
+      // B operand of this k-step (no LDS involved) and the slot's hand-over.  Waves 0-3 generate the operand BEFORE
+      // the barrier, waves 4-7 (their SIMD partners) AFTER it: between two barriers one partner is in its MFMAs while
+      // the other is in its VALU work, instead of both sharing the matrix pipe and then both leaving it idle
+      BFrag bf[KT];
+      auto operand = [&]() {
+        f32x4 x0[KT], x1[KT];
+        feature_tile(2 * kk, x0);
+        feature_tile(2 * kk + 1, x1);
+#pragma unroll
+        for (int c = 0; c < KT; ++c) split_pair(x0[c], x1[c], bf[c]);
+      };
+      const bool early = !MPNN_FEAT_STAGGER || wave < FEAT_WAVES / 2;
+      if (early) operand();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the images in flight have landed
+      __syncthreads();
+      if (step + R - 1 < n_steps) fill(step + R - 1);  // into the slot the previous k-step read
+      if (!early) operand();
+      const h8* slot = ring + (step % R) * FEAT_KSTEP_H8;
+#pragma unroll
+      for (int to = 0; to < MPNN_NT; ++to) {
+        const h8 a_hi = slot[(to * 2 + 0) * 64 + lane];
+#ifndef MPNN_FAST
+        const h8 a_lo = slot[(to * 2 + 1) * 64 + lane];
+#pragma unroll
+        for (int c = 0; c < KT; ++c) acc[to][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, bf[c].hi, acc[to][c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < KT; ++c) acc[to][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bf[c].lo, acc[to][c], 0, 0, 0);
+#endif
+#pragma unroll
+        for (int c = 0; c < KT; ++c) acc[to][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bf[c].hi, acc[to][c], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const size_t foff = (size_t)node * (MPNN_NT * KT * 64) + lane;
+    if (SAVE && has) {
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(acc[t][c], &E0_frag[foff + (t * KT + c) * 64]);
+    }
+    tile_layernorm<KT>(acc, ln_w, ln_b, lane);
+    if (SAVE && has) {
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(acc[t][c], &E_frag[foff + (t * KT + c) * 64]);
+    }
+    if (E_nat && has) {
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        const int e = 16 * c + col;
+        if (e < K) {
+          float* dst = E_nat + ((size_t)node * K + e) * MPNN_H + 4 * g;
+#pragma unroll
+          for (int t = 0; t < MPNN_NT; ++t) *reinterpret_cast<f32x4*>(dst + 16 * t) = acc[t][c];
+        }
+      }
+    }
+    BFrag eb[MPNN_NT / 2][KT];
+    tile_to_bfrag<MPNN_NT, KT, false>(acc, eb);
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(be + 16 * t + 4 * g);
+#pragma unroll
+      for (int c = 0; c < KT; ++c) acc[t][c] = bb;
+    }
+    split_gemm<KT, MPNN_NT / 2, 0, MPNN_NT>(wes, lane, eb, acc);
+    if (has) {
+      f32x4* out = reinterpret_cast<f32x4*>(hE) + (size_t)node * (MPNN_NT * KT * 64);
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(acc[t][c], &out[(t * KT + c) * 64 + lane]);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -573,7 +795,6 @@ MPNN_KERNELS_END
 // ===========================================================================
 // C ABI launchers (declared in include/mpnn_hip.h)
 // ===========================================================================
-static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 #ifndef MPNN_FAST
 extern "C" int mpnn_backbone_atoms(const float* X, const float* noise, const float* mask, int B, int L,
@@ -647,16 +868,24 @@ static int launch_edge_features(int A, const float* atoms, const int* E_idx, con
                                 const float* Wemb, const float* ln_w, const float* ln_b, const float* We,
                                 const float* be, int N, int L, int K, float* E_nat, float* hE, hipStream_t s,
                                 float* E0_frag = nullptr, float* E_frag = nullptr, const float* emb_bias = nullptr) {
-  dim3 grid(ceil_div(N, 4)), block(256);
+  // K <= 48: persistent workgroups with the weights staged through LDS; above, the streaming form (its four column
+  // tiles leave no registers for the gathered atoms)
+  constexpr bool ring = KT <= 3 && MPNN_FEAT_PERSISTENT;
+  dim3 grid(ring ? edge_grid(N, FEAT_WAVES) : ceil_div(N, 4)), block(ring ? FEAT_WAVES * 64 : 256);
 #define MPNN_FEAT_LAUNCH(AA, SV)                                                                                  \
-  hipLaunchKernelGGL((k_edge_features<KT, AA, SV>), grid, block, 0, s, atoms, E_idx, ridx, chain, pos_table, rbf_mu, \
-                     (const h8*)Wemb, ln_w, ln_b, (const h8*)We, be, N, L, K, E_nat, hE, (f32x4*)E0_frag,          \
-                     (f32x4*)E_frag, emb_bias)
+  if (ring)                                                                                                       \
+    hipLaunchKernelGGL((k_edge_features_ring<(KT <= 3 ? KT : 3), AA, SV>), grid, block, 0, s, atoms, E_idx, ridx, chain, \
+                       pos_table, rbf_mu, (const h8*)Wemb, ln_w, ln_b, (const h8*)We, be, N, L, K, E_nat, hE,     \
+                       (f32x4*)E0_frag, (f32x4*)E_frag, emb_bias);                                                \
+  else                                                                                                            \
+    hipLaunchKernelGGL((k_edge_features<KT, AA, SV>), grid, block, 0, s, atoms, E_idx, ridx, chain, pos_table, rbf_mu, \
+                       (const h8*)Wemb, ln_w, ln_b, (const h8*)We, be, N, L, K, E_nat, hE, (f32x4*)E0_frag,       \
+                       (f32x4*)E_frag, emb_bias)
   const bool save = E0_frag != nullptr;
   if (A == 5) {
-    if (save) MPNN_FEAT_LAUNCH(5, true); else MPNN_FEAT_LAUNCH(5, false);
+    if (save) { MPNN_FEAT_LAUNCH(5, true); } else { MPNN_FEAT_LAUNCH(5, false); }
   } else {
-    if (save) MPNN_FEAT_LAUNCH(6, true); else MPNN_FEAT_LAUNCH(6, false);
+    if (save) { MPNN_FEAT_LAUNCH(6, true); } else { MPNN_FEAT_LAUNCH(6, false); }
   }
 #undef MPNN_FEAT_LAUNCH
   MPNN_LAUNCH_CHECK();
@@ -769,7 +998,7 @@ k_feature_chunks(const float* __restrict__ atoms, const int* __restrict__ E_idx,
       if (T < A * A) {
         const f32x4 Ai = atom_i[T / A], Bj = atom_j[T % A];
         const float dx = Ai.x - Bj.x, dy = Ai.y - Bj.y, dz = Ai.z - Bj.z;
-        const float dist = sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
+        const float dist = rbf_distance(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float z = (dist - mu[r]) * 0.96089792702915982f;
