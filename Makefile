@@ -10,8 +10,10 @@ OBJS  := $(CSRC)/mpnn_featurizer.o $(CSRC)/mpnn_edge.o $(CSRC)/mpnn_edge_bwd.o $
 all: $(OUT)
 
 # neighbour search must round like the reference's separate ATen ops: no FMA contraction there
-$(CSRC)/mpnn_featurizer.o: $(CSRC)/mpnn_featurizer.hip $(CSRC)/mpnn_common.h
-	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $< -o $@
+# -fno-slp-vectorize: packed fp32 VALU forms occupy the issue port ~10 cycles next to MFMAs against 4.2 for the scalar
+# form (tools/ubench/coissue.hip); measured 0.318 -> 0.303 ms on mpnn_edge_features
+$(CSRC)/mpnn_featurizer.o: $(CSRC)/mpnn_featurizer.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h
+	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -fno-slp-vectorize -c $< -o $@
 
 $(CSRC)/mpnn_edge.o: $(CSRC)/mpnn_edge.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h $(CSRC)/mpnn_sample.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -43,8 +45,8 @@ $(CSRC)/mpnn_node_bwd.o: $(CSRC)/mpnn_node_bwd.hip $(CSRC)/mpnn_common.h $(CSRC)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 # second compilation of the forward kernels with one f16 product per fp32 product (entry points *_f16)
-$(CSRC)/mpnn_featurizer_f16.o: $(CSRC)/mpnn_featurizer.hip $(CSRC)/mpnn_common.h
-	$(HIPCC) $(HIPFLAGS) -DMPNN_FAST -ffp-contract=off -c $< -o $@
+$(CSRC)/mpnn_featurizer_f16.o: $(CSRC)/mpnn_featurizer.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h
+	$(HIPCC) $(HIPFLAGS) -DMPNN_FAST -ffp-contract=off -fno-slp-vectorize -c $< -o $@
 
 $(CSRC)/mpnn_edge_f16.o: $(CSRC)/mpnn_edge.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_edge_common.h $(CSRC)/mpnn_sample.h
 	$(HIPCC) $(HIPFLAGS) -DMPNN_FAST -c $< -o $@

@@ -342,9 +342,9 @@ k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, 
     for (int c = 0; c < KT; ++c) acc[t][c] = b0;
   }
 
-  float mu[4];
+  float muc[4];  // RBF centres times (1 / 1.25) sqrt(log2 e)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) mu[r] = rbf_mu[4 * g + r];
+  for (int r = 0; r < 4; ++r) muc[r] = rbf_mu[4 * g + r] * 0.96089792702915982f;
   const f32x4* atom_i = reinterpret_cast<const f32x4*>(atoms + (size_t)node * 24);
 
   // 16 RBFs (this lane: 4 of them) of atom pair p for each column tile
@@ -357,8 +357,8 @@ k_edge_features(const float* __restrict__ atoms, const int* __restrict__ E_idx, 
       const float d = rbf_distance(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float z = (d - mu[r]) * 0.96089792702915982f;  // (1 / 1.25) sqrt(log2 e)
-        x[c][r] = __builtin_amdgcn_exp2f(-(z * z));           // exp(-((d - mu) / 1.25)^2)
+        const float z = fmaf(d, 0.96089792702915982f, -muc[r]);  // (d - mu) (1 / 1.25) sqrt(log2 e), one instruction
+        x[c][r] = __builtin_amdgcn_exp2f(-(z * z));               // exp(-((d - mu) / 1.25)^2)
       }
     }
   };
@@ -501,9 +501,9 @@ k_edge_features_ring(const float* __restrict__ atoms, const int* __restrict__ E_
     if (s_ < n_steps) fill(s_);
   lds_fill(wes, We, WSPLIT);
 
-  float mu[4];
+  float muc[4];  // RBF centres times (1 / 1.25) sqrt(log2 e)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) mu[r] = rbf_mu[4 * g + r];
+  for (int r = 0; r < 4; ++r) muc[r] = rbf_mu[4 * g + r] * 0.96089792702915982f;
 
   int step = 0;
   for (int round = 0; round < n_rounds; ++round) {
@@ -547,8 +547,8 @@ k_edge_features_ring(const float* __restrict__ atoms, const int* __restrict__ E_
           const float d = rbf_distance(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float z = (d - mu[r]) * 0.96089792702915982f;  // (1 / 1.25) sqrt(log2 e)
-            x[c][r] = __builtin_amdgcn_exp2f(-(z * z));           // exp(-((d - mu) / 1.25)^2)
+            const float z = fmaf(d, 0.96089792702915982f, -muc[r]);  // (d - mu) (1 / 1.25) sqrt(log2 e), one instruction
+            x[c][r] = __builtin_amdgcn_exp2f(-(z * z));               // exp(-((d - mu) / 1.25)^2)
           }
         }
       } else if (tt == A * A) {
@@ -980,9 +980,9 @@ k_feature_chunks(const float* __restrict__ atoms, const int* __restrict__ E_idx,
   if (node >= N) return;
   const int g = lane >> 4, col = lane & 15;
   const int b = node / L, Kp = KT * 16;
-  float mu[4];
+  float muc[4];  // RBF centres times (1 / 1.25) sqrt(log2 e)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) mu[r] = rbf_mu[4 * g + r];
+  for (int r = 0; r < 4; ++r) muc[r] = rbf_mu[4 * g + r] * 0.96089792702915982f;
   const f32x4* atom_i = reinterpret_cast<const f32x4*>(atoms + (size_t)node * 24);
   const long long ri = residue_idx[node], ci = chain_labels[node];
   const size_t chunk = (size_t)N * MPNN_NT * KT * 64;
@@ -1001,7 +1001,7 @@ k_feature_chunks(const float* __restrict__ atoms, const int* __restrict__ E_idx,
         const float dist = rbf_distance(((dx * dx + dy * dy) + dz * dz) + 1e-6f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float z = (dist - mu[r]) * 0.96089792702915982f;
+          const float z = fmaf(dist, 0.96089792702915982f, -muc[r]);
           x[r] = __builtin_amdgcn_exp2f(-(z * z));
         }
       } else if (T < NTILE) {

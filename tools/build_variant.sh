@@ -4,7 +4,7 @@
 tag=$1; which=$2; shift 2
 C=mpnn_amd/csrc
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -I$C $@"
-[ "$which" = featurizer ] && F="$F -ffp-contract=off"
+[ "$which" = featurizer ] && F="$F -ffp-contract=off -fno-slp-vectorize"
 mkdir -p build/$tag variants
 /opt/rocm/bin/hipcc $F -c $C/mpnn_$which.hip -o build/$tag/v.o || exit 1
 OBJS=""
