@@ -338,8 +338,8 @@ struct WRing {
   h8 hi[D + 1], lo[D + 1];
 };
 
-template <int NKK, int NTO, int D>
-__device__ __forceinline__ void wring_load(WRing<D>& r, const h8* __restrict__ Wlane, int q) {
+template <int NKK, int NTO, int D, typename WP>
+__device__ __forceinline__ void wring_load(WRing<D>& r, WP Wlane, int q) {
   // Wlane = packed base + lane; fragment (to, kk) lives at ((to * NKK + kk) * 2 + part) * 64
   const int to = q % NTO, kk = q / NTO;
 #if defined(MPNN_ABL_WSTREAM_SAME)  // timing-only ablation builds (never shipped): every fragment read hits the same lines,
@@ -359,16 +359,16 @@ __device__ __forceinline__ void wring_load(WRing<D>& r, const h8* __restrict__ W
 #endif
 }
 
-template <int NKK, int NTO, int D>
-__device__ __forceinline__ void wring_prologue(WRing<D>& r, const h8* __restrict__ Wlane) {
+template <int NKK, int NTO, int D, typename WP>
+__device__ __forceinline__ void wring_prologue(WRing<D>& r, WP Wlane) {
 #pragma unroll
   for (int q = 0; q < D; ++q)
     if (q < NKK * NTO) wring_load<NKK, NTO, D>(r, Wlane, q);
 }
 
 // one k-step with streamed weights: Y[to][c] += W[to][kk] * B[c], to in [0, NTO)
-template <int KT, int NKK, int NTO, int D>
-__device__ __forceinline__ void split_kstep_stream(WRing<D>& r, const h8* __restrict__ Wlane, int kk,
+template <int KT, int NKK, int NTO, int D, typename WP>
+__device__ __forceinline__ void split_kstep_stream(WRing<D>& r, WP Wlane, int kk,
                                                    const BFrag (&B)[KT], f32x4 (&Y)[NTO][KT]) {
 #pragma unroll
   for (int to = 0; to < NTO; ++to) {
@@ -398,8 +398,8 @@ __device__ __forceinline__ void split_kstep_stream(WRing<D>& r, const h8* __rest
   }
 }
 
-template <int KT, int NKK, int NTO, int D>
-__device__ __forceinline__ void split_gemm_stream(const h8* __restrict__ Wlane, const BFrag (&B)[NKK][KT],
+template <int KT, int NKK, int NTO, int D, typename WP>
+__device__ __forceinline__ void split_gemm_stream(WP Wlane, const BFrag (&B)[NKK][KT],
                                                   f32x4 (&Y)[NTO][KT]) {
   WRing<D> r;
   wring_prologue<NKK, NTO, D>(r, Wlane);

@@ -94,6 +94,9 @@ MPNN_KERNELS_BEGIN
 #ifndef MPNN_UPD_ROWS
 #define MPNN_UPD_ROWS 2
 #endif
+#ifndef MPNN_UPD_W3_FLAT
+#define MPNN_UPD_W3_FLAT 0  // 1: W13's streamed halves by flat_load (round-2 form)
+#endif
 #ifndef MPNN_UPD_RES_SPREAD
 #define MPNN_UPD_RES_SPREAD 1
 #endif
@@ -493,8 +496,16 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
     const int nxt = (node + stride < Nend) ? node + stride : Nend - 1;
     STAMP(7);
     const h8* W3u = W13;
+#if MPNN_UPD_W3_FLAT
+    LAUNDER_FLAT(W3u);
+#else
     LAUNDER(W3u);
+#endif
+#if MPNN_UPD_W3_FLAT
     const h8* W3g = W3u + lane;
+#else
+    const auto W3g = GLOBAL(W3u) + lane;
+#endif
     f32x4* x = hE + (size_t)node * (MPNN_NT * KT * 64) + lane;
     f32x4 p[MPNN_NT];  // P'_i: needed only after layer 1, loaded during its last k-step
     const float* Pi = Pb + (size_t)node * ldp + offP + 4 * g;

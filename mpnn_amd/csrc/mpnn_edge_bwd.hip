@@ -122,6 +122,18 @@ k_message_bwd(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, con
 // LayerNorm parameter gradients are reduced per workgroup in LDS, then added to dln[0:128] (weight) and
 // dln[128:256] (bias) with one atomic per entry and workgroup.
 // ---------------------------------------------------------------------------
+// W11b^T stream of the edge-update backward: fragments in flight ahead of their MFMAs, and the pointer's address space
+#ifndef MPNN_BWD_W1_RING
+#define MPNN_BWD_W1_RING 3
+#endif
+#ifndef MPNN_BWD_W1_GLOBAL
+#define MPNN_BWD_W1_GLOBAL 0  // 1: global_load stream (measured slower, see LAUNDER_FLAT)
+#endif
+#if MPNN_BWD_W1_GLOBAL
+#define MPNN_BWD_W1_PTR(p) GLOBAL(p)
+#else
+#define MPNN_BWD_W1_PTR(p) (p)
+#endif
 template <int KT>
 __global__ void __launch_bounds__(MPNN_BWD_WAVES * 64)
 k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __restrict__ a2,
@@ -147,7 +159,11 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
   for (int node = blockIdx.x * MPNN_BWD_WAVES + wave; node < N; node += stride) {
     LAUNDER(ln_w);
     const h8* W1u = W11bT;
+#if MPNN_BWD_W1_GLOBAL
     LAUNDER(W1u);
+#else
+    LAUNDER_FLAT(W1u);
+#endif
     const size_t off = (size_t)node * (MPNN_NT * KT * 64) + lane;
     f32x4 x[MPNN_NT][KT], d[MPNN_NT][KT];
 #pragma unroll
@@ -196,7 +212,7 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
     un = grad_to_bfrag<KT>(d, db, &amax_l[2]);
     // ---- de = dz (residual) + W11b^T da1 ; W11b^T streams from L2
     zero_tile<KT>(x);
-    split_gemm_stream<KT, NKK, MPNN_NT, 3>(W1u + lane, db, x);
+    split_gemm_stream<KT, NKK, MPNN_NT, MPNN_BWD_W1_RING>(MPNN_BWD_W1_PTR(W1u) + lane, db, x);
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll

@@ -1,11 +1,29 @@
 // Helpers shared by the forward (mpnn_edge.hip) and backward (mpnn_edge_bwd.hip) per-edge kernels.
 #pragma once
 #include "mpnn_common.h"
+#include <type_traits>
 
 namespace {
 // make a (uniform) pointer opaque once per loop iteration: keeps LICM from hoisting hundreds of
 // loop-invariant weight / bias loads out of the persistent loop and pinning them in registers
+// The opaque value is a ZERO OFFSET added to the pointer, not the pointer itself: laundering the pointer also hides
+// where it came from (a kernel argument = global memory), and hipcc then emits flat_load for everything read through
+// it.  Flat loads count on lgkmcnt as well as vmcnt, so every "wait for my LDS read" behind one waits for an L2 / HBM
+// round trip too (measured on the edge update's W13 ring).  GLOBAL(p) states the address space outright.
+// LAUNDER_FLAT: the pointer itself goes through the asm; reads through it become flat_load.  Kept for ONE stream, the
+// edge-update backward's W11b^T ring, where the flat form measured FASTER (1.665 against 1.81 ms per training step).
+#define LAUNDER_FLAT(p) asm volatile("" : "+s"(p))
+#ifdef MPNN_LAUNDER_PTR  // round-1 form everywhere (A/B builds)
 #define LAUNDER(p) asm volatile("" : "+s"(p))
+#else
+#define LAUNDER(p)                                    \
+  do {                                                \
+    int z__;                                          \
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z__));      \
+    (p) += z__;                                       \
+  } while (0)
+#endif
+#define GLOBAL(p) ((const __attribute__((address_space(1))) std::remove_cv_t<std::remove_pointer_t<decltype(p)>>*)(p))
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 
 __device__ __forceinline__ void lds_fill(h8* dst, const h8* __restrict__ src, int n) {
