@@ -606,6 +606,27 @@ def main():
                   "bit_identical": bool(torch.equal(rates["shared"][1], rates["repeated"][1])),
                   "note": "featurizer + encoder once per distinct structure (mpnn_dec_message_shared); SURVEY 8f N2"}
     log("shared-structure leg done")
+    # ---- secondary: the same forward replayed as ONE HIP graph (mpnn_amd.graphs.GraphedForward): what the ~26 launch gaps cost
+    graphed = None
+    if not a.no_f16_leg:
+        try:
+            from mpnn_amd.graphs import GraphedForward
+            gf = GraphedForward(model, *args, b["fix_order"])
+            for _ in range(3):
+                gf.graph.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                gf.graph.replay()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / a.steps
+            graphed = {"residues_per_s": round(B * L / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+                       "bit_identical_to_eager": bool(torch.equal(gf.out, out)),
+                       "note": "per rank; one graph launch per forward instead of ~26 kernel launches; `value` above is the eager path"}
+            del gf
+        except Exception as e:  # the graph path is an extra: never let it take the line down
+            graphed = {"error": repr(e)[:200]}
+    log("graph-replay leg done")
     # ---- secondary: BASELINE configs[0] stand-in (C1): ragged token-budget batches of 100 chains, forward only
     c1 = None
     if not a.no_f16_leg:
@@ -688,6 +709,8 @@ def main():
             "c1_forward": c1,
             "sparse_forward": sparse,
         }
+        if graphed:
+            line["forward_hip_graph"] = graphed
         line["forward_f16_products"] = dict(f16, note="per-rank; one f16 MFMA product per fp32 product instead of three; "
                                             "fp32 accumulate / GELU / LayerNorm; tolerance in include/mpnn_hip.h")
         if train is not None:
