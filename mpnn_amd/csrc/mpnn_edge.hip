@@ -338,15 +338,22 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
       for (int c = 0; c < KT; ++c) h1[t][c] = DEC ? (h1[t][c] * s[c] + p[t]) : (h1[t][c] + p[t]);
-    if (SAVE) {
+    BFrag hb[NKK][KT];
+    if (SAVE) {  // the saved pre-activation goes out six stores per k-step of the GELU + split, not as one burst of 24
       f32x4* o = sv1 + (size_t)node * (MPNN_NT * KT * 64) + lane;
 #pragma unroll
-      for (int t = 0; t < MPNN_NT; ++t)
+      for (int kk = 0; kk < NKK; ++kk) {
 #pragma unroll
-        for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(h1[t][c], &o[(t * KT + c) * 64]);
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(h1[2 * kk + u][c], &o[((2 * kk + u) * KT + c) * 64]);
+#pragma unroll
+        for (int c = 0; c < KT; ++c) split_pair(gelu4(h1[2 * kk][c]), gelu4(h1[2 * kk + 1][c]), hb[kk][c]);
+        FENCE();
+      }
+    } else {
+      tile_to_bfrag<MPNN_NT, KT, true>(h1, hb);
     }
-    BFrag hb[NKK][KT];
-    tile_to_bfrag<MPNN_NT, KT, true>(h1, hb);
     STAMP(1);
     // next residue's scalars (their loads fly under layer 2)
     const float* rown[KT];
@@ -361,6 +368,12 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
     }
     lds_gemm<KT>(W2s, lane, hb, y);
     STAMP(2);
+    // (training: the second saved pre-activation leaves row tile by row tile inside the reduction below)
+    // h1 is free: the next residue's gathered rows and its first hE k-step are issued a few loads per row tile of the
+    // GELU + reduction below, not as one burst: 30 back-to-back loads (16 rows each) fill the address unit's queue and
+    // the wave then waits at the ISSUE of the later ones (measured with MPNN_STAMP: 12 % of the kernel); the k-step
+    // starts once half of y has been reduced (registers)
+#if MPNN_MSG_BURST
     if (SAVE) {
       f32x4* o = sv2 + (size_t)node * (MPNN_NT * KT * 64) + lane;
 #pragma unroll
@@ -368,11 +381,6 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 #pragma unroll
         for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(y[t][c], &o[(t * KT + c) * 64]);
     }
-    // h1 is free: the next residue's gathered rows and its first hE k-step are issued a few loads per row tile of the
-    // GELU + reduction below, not as one burst: 30 back-to-back loads (16 rows each) fill the address unit's queue and
-    // the wave then waits at the ISSUE of the later ones (measured with MPNN_STAMP: 12 % of the kernel); the k-step
-    // starts once half of y has been reduced (registers)
-#if MPNN_MSG_BURST
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
@@ -383,6 +391,11 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 #if MPNN_MSG_BURST
       if (t == MPNN_NT / 2) load_kstep<KT>(edge_block(nxt), 0, x0);
 #else
+      if (SAVE) {
+        f32x4* o = sv2 + (size_t)node * (MPNN_NT * KT * 64) + lane;
+#pragma unroll
+        for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(y[t][c], &o[(t * KT + c) * 64]);
+      }
 #pragma unroll
       for (int c = 0; c < KT; ++c) h1[t][c] = row_tile(rown[c], t);
       // the k-step's 2 KT tiles over MPNN_X0_SPAN row tiles from MPNN_X0_FIRST on (a dead y tile frees half a k-step
@@ -529,14 +542,22 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #pragma unroll
       for (int c = 0; c < KT; ++c) h1[t][c] += p[t];
     const size_t soff = (size_t)node * (MPNN_NT * KT * 64) + lane;
-    if (SAVE) {
-#pragma unroll
-      for (int t = 0; t < MPNN_NT; ++t)
-#pragma unroll
-        for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(h1[t][c], &sv1[soff + (t * KT + c) * 64]);
-    }
     BFrag hb[NKK][KT];
-    tile_to_bfrag<MPNN_NT, KT, true>(h1, hb);
+    if (SAVE) {  // saved pre-activation: six stores per k-step of the GELU + split instead of one burst of 24
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int c = 0; c < KT; ++c)
+            __builtin_nontemporal_store(h1[2 * kk + u][c], &sv1[soff + ((2 * kk + u) * KT + c) * 64]);
+#pragma unroll
+        for (int c = 0; c < KT; ++c) split_pair(gelu4(h1[2 * kk][c]), gelu4(h1[2 * kk + 1][c]), hb[kk][c]);
+        FENCE();
+      }
+    } else {
+      tile_to_bfrag<MPNN_NT, KT, true>(h1, hb);
+    }
     STAMP(1);
     const float* rown[KT];
     setup(nxt, rown);
@@ -549,12 +570,14 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
     }
     lds_gemm<KT>(W2s, lane, hb, h2);
     STAMP(2);
+#if !MPNN_UPD_RES_SPREAD
     if (SAVE) {
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
         for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(h2[t][c], &sv2[soff + (t * KT + c) * 64]);
     }
+#endif
     // W13 stream: lo halves (and the hi halves of the fragments that do not fit into LDS), D steps ahead
     constexpr int D = MPNN_UPD_RING;
     constexpr int NQ = NKK * MPNN_NT;
@@ -585,6 +608,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #else
           h1[t][c] = SAVE ? f32x4{0.f, 0.f, 0.f, 0.f} : x[(t * KT + c) * 64];
 #endif
+          if (SAVE) __builtin_nontemporal_store(h2[t][c], &sv2[soff + (t * KT + c) * 64]);
         }
 #pragma unroll
       for (int c = 0; c < KT; ++c) split_pair(gelu4(h2[2 * kk][c]), gelu4(h2[2 * kk + 1][c]), hb[kk][c]);

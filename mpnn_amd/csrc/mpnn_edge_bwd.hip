@@ -15,6 +15,9 @@
 #include "mpnn_bwd_common.h"
 
 #define MPNN_BWD_WAVES 8
+#ifndef MPNN_BWD_BATCH_LOADS
+#define MPNN_BWD_BATCH_LOADS 1
+#endif
 
 // y <- y * gelu'(a) with a streamed from the saved pre-activations; per-feature sums over the residue's edges
 // go to dP (the h_i projection's gradient); the (optionally s-scaled) rows are written row-major for the gather
@@ -23,12 +26,26 @@ __device__ __forceinline__ void first_layer_grad(f32x4 (&y)[MPNN_NT][KT], float 
                                                  const float (&s)[KT], float* __restrict__ dP, float* __restrict__ nat,
                                                  int lane) {
   const int g = lane >> 4, col = lane & 15;
+#if MPNN_BWD_BATCH_LOADS
+  // the whole saved tensor of the residue in flight at once (the B fragments of the GEMM before are dead: registers),
+  // pinned ahead of the arithmetic: tile-by-tile the wave paid one HBM round trip per row tile
+  f32x4 av[MPNN_NT][KT];
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+    for (int c = 0; c < KT; ++c) av[t][c] = __builtin_nontemporal_load(&a[(t * KT + c) * 64]);
+  FENCE();
+#endif
 #pragma unroll
   for (int t = 0; t < MPNN_NT; ++t) {
     f32x4 ps = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
+#if MPNN_BWD_BATCH_LOADS
+      y[t][c] *= gelu_grad4(av[t][c]) * unscale;
+#else
       y[t][c] *= gelu_grad4(__builtin_nontemporal_load(&a[(t * KT + c) * 64])) * unscale;
+#endif
       ps += y[t][c];
       if (SCALE) y[t][c] *= s[c];
       __builtin_nontemporal_store(y[t][c], reinterpret_cast<f32x4*>(nat + (size_t)(16 * c + col) * MPNN_H + 16 * t + 4 * g));
@@ -83,12 +100,23 @@ k_message_bwd(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, con
     f32x4 d[MPNN_NT][KT];
     {
       const float* dg = dgsum + (size_t)node * MPNN_H + 4 * g;
+#if MPNN_BWD_BATCH_LOADS
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) d[t][c] = __builtin_nontemporal_load(&a2[off + (t * KT + c) * 64]);
+      FENCE();
+#endif
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t) {
         const f32x4 gs = row_tile(dg, t);
 #pragma unroll
         for (int c = 0; c < KT; ++c) {
+#if MPNN_BWD_BATCH_LOADS
+          d[t][c] = gelu_grad4(d[t][c]) * (gs * w[c]);
+#else
           d[t][c] = gelu_grad4(__builtin_nontemporal_load(&a2[off + (t * KT + c) * 64])) * (gs * w[c]);
+#endif
           __builtin_nontemporal_store(d[t][c], &da2[off + (t * KT + c) * 64]);
         }
         FENCE();
@@ -104,6 +132,25 @@ k_message_bwd(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, con
     un = grad_to_bfrag<KT>(y, db, &amax_l[1]);
     zero_tile<KT>(d);
     split_gemm<KT, NKK, 0, MPNN_NT>(W1s, lane, db, d);
+#if MPNN_BWD_BATCH_LOADS
+    if (accumulate) {  // uniform
+      f32x4 prev[MPNN_NT][KT];
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) prev[t][c] = dE[off + (t * KT + c) * 64];
+      FENCE();
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(d[t][c] * un + prev[t][c], &dE[off + (t * KT + c) * 64]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(d[t][c] * un, &dE[off + (t * KT + c) * 64]);
+    }
+#else
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
@@ -112,6 +159,7 @@ k_message_bwd(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, con
         if (accumulate) v += dE[off + (t * KT + c) * 64];
         __builtin_nontemporal_store(v, &dE[off + (t * KT + c) * 64]);
       }
+#endif
   }
   __syncthreads();
   if (threadIdx.x < 2) atomicMax(amax + threadIdx.x, amax_l[threadIdx.x]);
@@ -191,6 +239,25 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
     // ---- through W13, gelu'(a2)
     zero_tile<KT>(x);
     split_gemm<KT, NKK, 0, MPNN_NT>(W3s, lane, db, x);
+#if MPNN_BWD_BATCH_LOADS
+    {
+      f32x4 av[MPNN_NT][KT];  // db is dead: registers for the whole saved tensor in flight at once
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) av[t][c] = __builtin_nontemporal_load(&a2[off + (t * KT + c) * 64]);
+      FENCE();
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t) {
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+          x[t][c] *= gelu_grad4(av[t][c]) * un;
+          __builtin_nontemporal_store(x[t][c], &da2_out[off + (t * KT + c) * 64]);
+        }
+        FENCE();
+      }
+    }
+#else
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
 #pragma unroll
@@ -200,6 +267,7 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
       }
       FENCE();
     }
+#endif
     un = grad_to_bfrag<KT>(x, db, &amax_l[1]);
     // ---- through W12, gelu'(a1)
     zero_tile<KT>(d);
@@ -213,6 +281,21 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
     // ---- de = dz (residual) + W11b^T da1 ; W11b^T streams from L2
     zero_tile<KT>(x);
     split_gemm_stream<KT, NKK, MPNN_NT, MPNN_BWD_W1_RING>(MPNN_BWD_W1_PTR(W1u) + lane, db, x);
+#if MPNN_BWD_BATCH_LOADS
+    {
+      const f32x4* rsrc = drop_thresh ? dE : dz_out;
+      f32x4 res[MPNN_NT][KT];
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) res[t][c] = rsrc[off + (t * KT + c) * 64];
+      FENCE();
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(x[t][c] * un + res[t][c], &dE[off + (t * KT + c) * 64]);
+    }
+#else
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
@@ -220,6 +303,7 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
         const f32x4 res = drop_thresh ? dE[off + (t * KT + c) * 64] : dz_out[off + (t * KT + c) * 64];
         __builtin_nontemporal_store(x[t][c] * un + res, &dE[off + (t * KT + c) * 64]);
       }
+#endif
   }
   __syncthreads();
   if (threadIdx.x < 2 * MPNN_H) unsafeAtomicAdd(dln + threadIdx.x, lnacc[threadIdx.x]);
