@@ -653,6 +653,16 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #pragma unroll
       for (int c = 0; c < KT; ++c) h2[t][c] = row_tile(rown[c], t);
 #endif
+    // training: the residual is added after the dropout; its tiles are all requested here, in one batch (layer 3's B
+    // fragments are dead: registers), not one row tile at a time behind the gathers below
+    f32x4 rs[SAVE ? MPNN_NT : 1][KT];
+    if (SAVE) {
+#pragma unroll
+      for (int t = 0; t < MPNN_NT; ++t)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) rs[SAVE ? t : 0][c] = x[(t * KT + c) * 64];
+      FENCE();
+    }
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
 #if MPNN_UPD_ROWS == 2  // a few gathers per row tile instead of one burst of 24 (see the message kernel)
@@ -669,7 +679,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
         if (SAVE) {
           if (drop_thresh)
             h1[t][c] = dropout4(h1[t][c], (unsigned)(soff + (t * KT + c) * 64) * 4u, drop_seed, drop_thresh, inv_keep);
-          h1[t][c] += x[(t * KT + c) * 64];
+          h1[t][c] += rs[SAVE ? t : 0][c];
           __builtin_nontemporal_store(h1[t][c], &svz[soff + (t * KT + c) * 64]);
         }
       }
