@@ -112,7 +112,7 @@ MPNN_KERNELS_BEGIN
 #define MPNN_X_PREFETCH 0
 #endif
 #ifndef MPNN_UPD_RING
-#define MPNN_UPD_RING 7  // W13 lo fragments in flight ahead of their MFMAs (edge update, layer 3)
+#define MPNN_UPD_RING 4  // W13 lo fragments in flight ahead of their MFMAs (edge update, layer 3; 7 -> 4: 26 -> 6 spilled registers, -2 %)
 #endif
 
 // layer 1 of every edge MLP: acc += W1b * hE[node]; hE feature tiles stream from HBM one k-step
