@@ -391,6 +391,17 @@ __device__ __forceinline__ f32x4 quad_transpose(f32x4 v) {
   return v;
 }
 
+#ifndef MPNN_WGRAD_NT
+#define MPNN_WGRAD_NT 1  // operand streams by non-temporal loads
+#endif
+#if MPNN_WGRAD_NT
+#define WGRAD_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define WGRAD_LOAD(p) (*(p))
+#endif
+#ifndef MPNN_WGRAD_CONTIG
+#define MPNN_WGRAD_CONTIG 0  // 1: a workgroup walks a contiguous range of residues instead of a grid stride
+#endif
 template <bool A_NAT, bool B_GELU>
 __global__ void __launch_bounds__(256)
 k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigned* __restrict__ amax, int N, int KT,
@@ -418,25 +429,32 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
       for (int c = 0; c < 3; ++c) {
         if (c < KT) {
           if (A_NAT)
-            va[tt][c] = __builtin_nontemporal_load(
+            va[tt][c] = WGRAD_LOAD(
                 reinterpret_cast<const f32x4*>(A + ((size_t)node * Kp + 16 * c + col) * MPNN_H + 16 * t + 4 * g));
           else
-            va[tt][c] = __builtin_nontemporal_load(&Af[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane]);
-          vb[tt][c] = __builtin_nontemporal_load(&Bf[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane]);
+            va[tt][c] = WGRAD_LOAD(&Af[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane]);
+          vb[tt][c] = WGRAD_LOAD(&Bf[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane]);
         }
       }
     }
   };
+#if MPNN_WGRAD_CONTIG
+  const int per = (N + gridDim.x - 1) / gridDim.x;
+  int node = blockIdx.x * per;
+  const int Nend = min(N, node + per), nstep = 1;
+#else
   int node = blockIdx.x;
-  if (node < N) fetch(node);
-  for (; node < N; node += gridDim.x) {
+  const int Nend = N, nstep = gridDim.x;
+#endif
+  if (node < Nend) fetch(node);
+  for (; node < Nend; node += nstep) {
 #ifdef MPNN_ABL_WGRAD_STREAM  // timing-only ablation build (never shipped): the operand streams alone
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int c = 0; c < 3; ++c)
         if (c < KT) acc[tt][c] += va[tt][c] * vb[tt][c];
-    if (node + (int)gridDim.x < N) fetch(node + gridDim.x);
+    if (node + nstep < Nend) fetch(node + nstep);
     continue;
 #endif
     __syncthreads();  // previous residue's operand reads are done
@@ -471,7 +489,7 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
       }
     }
     __syncthreads();
-    if (node + (int)gridDim.x < N) fetch(node + gridDim.x);  // next residue's loads fly under the MFMAs
+    if (node + nstep < Nend) fetch(node + nstep);  // next residue's loads fly under the MFMAs
     for (int c = 0; c < KT; ++c) {
       h4 ah[2], al[2];
 #pragma unroll
