@@ -1213,12 +1213,30 @@ struct LevelLayer {  // one decoder layer of the device-side plan (mpnn_decode_p
   float* hV_out; float* PQ;
 };
 static_assert(sizeof(LevelLayer) * 4 <= MPNN_DECODE_PLAN_BYTES, "mpnn_hip.h: MPNN_DECODE_PLAN_BYTES too small");
+// The kernel's view of the same bytes: every pointer typed as GLOBAL memory.  A pointer loaded from memory has no
+// known address space, and through the plain struct every weight stream and row read of the kernel became a
+// flat_load (229 of them), which count on lgkmcnt: each wait for an LDS read then also waited for the streams.
+#define MPNN_GP(T) const __attribute__((address_space(1))) T*
+struct LevelLayerG {
+  MPNN_GP(float) P; int ldp, offP;
+  __attribute__((address_space(1))) float* A; int lda, offA;
+  int offEnc;
+  MPNN_GP(h8) W1b; MPNN_GP(h8) W2; MPNN_GP(float) b2;
+  MPNN_GP(float) hV_in;
+  MPNN_GP(h8) W3; MPNN_GP(float) b3; MPNN_GP(float) ln1w; MPNN_GP(float) ln1b;
+  MPNN_GP(h8) Win; MPNN_GP(float) bin;
+  MPNN_GP(h8) Wout; MPNN_GP(float) bout; MPNN_GP(float) ln2w; MPNN_GP(float) ln2b;
+  float inv_scale;
+  MPNN_GP(h8) Wproj; MPNN_GP(float) bproj; int nproj;
+  __attribute__((address_space(1))) float* hV_out; __attribute__((address_space(1))) float* PQ;
+};
+static_assert(sizeof(LevelLayerG) == sizeof(LevelLayer), "LevelLayerG must mirror LevelLayer");
 
 __global__ void __launch_bounds__(MPNN_MSGT_WAVES * 64)
 k_decode_level(const f32x4* __restrict__ hE, const float* __restrict__ PVenc, int ldenc, const int* __restrict__ rank,
                const int* __restrict__ E_idx, const float* __restrict__ mask, const float* __restrict__ edge_mask,
                const int* __restrict__ node_list, int n_list, int enc_mod, int L, int K, int KT, float cnt_const,
-               const LevelLayer* __restrict__ plan, int n_layers, const f32x4* __restrict__ Wlogit,
+               const LevelLayerG* __restrict__ plan, int n_layers, const f32x4* __restrict__ Wlogit,
                const float* __restrict__ blogit,
                const float* __restrict__ logit_bias, int n_letters, float inv_temperature, unsigned long long seed,
                const float* __restrict__ designable, const long long* __restrict__ S_in, long long* __restrict__ S_out,
@@ -1237,7 +1255,7 @@ k_decode_level(const f32x4* __restrict__ hE, const float* __restrict__ PVenc, in
   LevelItem it;
   STAMP(0);
   for (int l = first_layer; l < n_layers; ++l) {
-    const LevelLayer y = plan[l];  // uniform: scalar loads
+    const LevelLayerG y = plan[l];  // uniform: scalar loads
     // an opaque zero in every LDS address of the iteration: without it the ~100 (lane, constant) address sums of the
     // body are hoisted out of the layer loop and live - spilled to scratch - across it
     int zero;
@@ -1245,27 +1263,27 @@ k_decode_level(const f32x4* __restrict__ hE, const float* __restrict__ PVenc, in
     h8* lds = lds_base + zero;
     float (*gsl)[MPNN_H] = gsl_base + zero;
     LdsFill f1, f2;
-    lds_fill_issue(f1, y.W1b);
+    lds_fill_issue(f1, (const h8*)y.W1b);
     if (l == first_layer) {  // later layers: W2 was staged during the previous node phase
-      lds_fill_issue(f2, y.W2);
+      lds_fill_issue(f2, (const h8*)y.W2);
       level_item_setup(it, hE, rank, E_idx, mask, edge_mask, node_list, tile, lvn, nlive, enc_mod, L, K, KT);
     }
     f32x4 xt[MPNN_NT], h1[MPNN_NT][1];
-    level_rows_load(it, y.A, y.lda, y.offA, PVenc, ldenc, y.offEnc, xt, h1);
+    level_rows_load(it, (float*)y.A, y.lda, y.offA, PVenc, ldenc, y.offEnc, xt, h1);
     W3Frags w3;
-    if (wave < LV_NODE_WAVES) w3_prefetch(w3, y.W3);
+    if (wave < LV_NODE_WAVES) w3_prefetch(w3, (const h8*)y.W3);
     lds_fill_commit(f1, lds);
     if (l == first_layer) lds_fill_commit(f2, lds + WSPLIT);
     for (int i = threadIdx.x; i < 16 * MPNN_H; i += blockDim.x) (&gsl[0][0])[i] = 0.f;
     __syncthreads();
     STAMP(1);
-    if (it.has) level_message(it, lds, lds + WSPLIT, y.b2, y.P, y.ldp, y.offP, xt, h1, gsl);
+    if (it.has) level_message(it, lds, lds + WSPLIT, (const float*)y.b2, (const float*)y.P, y.ldp, y.offP, xt, h1, gsl);
     STAMP(2);
     __syncthreads();  // neighbour sums complete; the message weights in LDS are dead from here on
     STAMP(3);
     if (wave >= LV_NODE_WAVES && l + 1 < n_layers) {
       // the four waves without node work stage the next layer's W2 (upper half of lds; ex covers the lower half)
-      const h8* src = plan[l + 1].W2;
+      const h8* src = (const h8*)plan[l + 1].W2;
       constexpr int NT = (MPNN_MSGT_WAVES - LV_NODE_WAVES) * 64;
       const int t0 = threadIdx.x - LV_NODE_WAVES * 64;
       for (int i0 = t0; i0 < WSPLIT; i0 += 8 * NT) {
@@ -1276,8 +1294,8 @@ k_decode_level(const f32x4* __restrict__ hE, const float* __restrict__ PVenc, in
         for (int u = 0; u < 8; ++u) lds[WSPLIT + i0 + u * NT] = v[u];
       }
     }
-    level_node(lds, gsl, w3, node_list, n_list, tile, lvn, mask, y.hV_in, cnt_const, y.b3, y.ln1w, y.ln1b, y.Win, y.bin,
-               y.Wout, y.bout, y.ln2w, y.ln2b, y.inv_scale, y.Wproj, y.bproj, y.nproj, y.hV_out, y.PQ);
+    level_node(lds, gsl, w3, node_list, n_list, tile, lvn, mask, (const float*)y.hV_in, cnt_const, (const float*)y.b3, (const float*)y.ln1w, (const float*)y.ln1b, (const h8*)y.Win, (const float*)y.bin,
+               (const h8*)y.Wout, (const float*)y.bout, (const float*)y.ln2w, (const float*)y.ln2b, y.inv_scale, (const h8*)y.Wproj, (const float*)y.bproj, y.nproj, (float*)y.hV_out, (float*)y.PQ);
     STAMP(4);
     // the tile's hV / P rows written above are read by the next layer (or the head) of this workgroup, and the next
     // layer's LDS fill overwrites the exchange buffer
@@ -1289,11 +1307,11 @@ k_decode_level(const f32x4* __restrict__ hE, const float* __restrict__ PVenc, in
     const int col = lane & 15, idx = tile * lvn + col;
     const bool live = col < lvn && idx < n_list;
     const int nd = node_list[live ? idx : n_list - 1];
-    sample_columns(plan[n_layers - 1].hV_out, Wlogit, blogit, logit_bias, n_letters, nd, live, inv_temperature, seed,
+    sample_columns((const float*)plan[n_layers - 1].hV_out, Wlogit, blogit, logit_bias, n_letters, nd, live, inv_temperature, seed,
                    designable, S_in, S_out, log_probs, pr, pick, lane);
   }
   __syncthreads();
-  fold_sequence_rows<MPNN_MSGT_WAVES, 2>([&](int l, int n) { return plan[l].A + (size_t)n * plan[l].lda + plan[l].offA; },
+  fold_sequence_rows<MPNN_MSGT_WAVES, 2>([&](int l, int n) { return (float*)plan[l].A + (size_t)n * plan[l].lda + plan[l].offA; },
                                          n_layers, TS, ld_ts, node_list + tile * lvn, nlive, pick, wave, lane);
   STAMP(6);
 #ifdef MPNN_STAMP
@@ -1486,7 +1504,7 @@ extern "C" int MPNN_API(mpnn_decode_level)(const float* hE_frag, const float* PV
   const int lvn = level_nodes_per_wg(n_list);
   hipLaunchKernelGGL(k_decode_level, dim3(ceil_div(n_list, lvn)), dim3(MPNN_MSGT_WAVES * 64), 0, (hipStream_t)stream,
                      (const f32x4*)hE_frag, PVenc, ldenc, rank, E_idx32, mask, edge_mask, node_list, n_list, enc_nodes, L,
-                     K, KT, cnt_const, (const LevelLayer*)plan_dev, n_layers, (const f32x4*)Wlogit_packed, logit_b,
+                     K, KT, cnt_const, (const LevelLayerG*)plan_dev, n_layers, (const f32x4*)Wlogit_packed, logit_b,
                      logit_bias, n_letters, 1.0f / temperature, (unsigned long long)seed, designable,
                      (const long long*)S_in, (long long*)S_out, log_probs, TS, ld_ts, lvn, first_layer);
   MPNN_LAUNCH_CHECK();
