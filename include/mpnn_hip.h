@@ -87,7 +87,10 @@ int mpnn_occupancy(const float* atoms, const float* mask, int B, int L, float cu
 
 /* RBF (:291-307, :344-347) + positional (:349-356) features -> edge_embedding + norm_edges (:357-359) -> W_e (:464).
  * n_atoms 5 or 6 (virtual centre).  Wemb_packed from edge_embedding.weight [128, 16+16*n_atoms^2];
- * rbf_mu = the 16 Gaussian centres.  E_natural [B,L,K,128] (the reference's `E`) may be NULL. */
+ * rbf_mu = the 16 Gaussian centres.  E_natural [B,L,K,128] (the reference's `E`) may be NULL.
+ * The RBF distances use the hardware square root (1 ulp; a feature moves by < 2e-6 relative) - only mpnn_knn_topk,
+ * whose ranks must equal the reference's, needs the correctly rounded one.  K <= 48 runs as persistent workgroups
+ * with the weights staged through LDS, K <= 64 with the weights streamed per residue; same results bit for bit. */
 int mpnn_edge_features(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
                        const int64_t* chain_labels, const float* pos_table, const float* rbf_mu,
                        const float* Wemb_packed, const float* ln_w, const float* ln_b, const float* We_packed,
@@ -367,7 +370,9 @@ int mpnn_pack_blocks(const float* const* blocks, const int* ld, const int* trans
                      void* stream);
 
 /* Weight / bias gradient of an nn.Linear over per-residue rows (autograd of the node-level linears, :78-93, :151-155):
- * dW[o][i] += sum_n dY[n][o] X[n][i]  (row strides ldy, ldx, ldw; fp32 products), dbias[o] += sum_n dY[n][o].
+ * dW[o][i] += sum_n dY[n][o] X[n][i]  (row strides ldy, ldx, ldw), dbias[o] += sum_n dY[n][o].  Products as three
+ * f16-split MFMA terms with fp32 accumulation (relative error per product <= ~2^-21); each 32-row batch of dY is scaled
+ * by a power of two taken from its largest magnitude, so gradients of any size keep that precision; |X| < 65504.
  * Accumulates: zero dW / dbias first.  dbias may be NULL.  workspace: device scratch, 16512 floats per 128x128 output
  * block and row chunk (256 chunks per block fill the chip). */
 int mpnn_node_wgrad(const float* dY, int ldy, int out_f, const float* X, int ldx, int in_f, int n_rows, float* dW,
