@@ -410,6 +410,21 @@ __device__ __forceinline__ void split_gemm_stream(WP Wlane, const BFrag (&B)[NKK
   }
 }
 
+// the same with a hook at the top of every k-step (loads the caller wants spread over the GEMM, not issued as a burst)
+template <int KT, int NKK, int NTO, int D, typename WP, typename Hook>
+__device__ __forceinline__ void split_gemm_stream_hook(WP Wlane, const BFrag (&B)[NKK][KT], f32x4 (&Y)[NTO][KT],
+                                                       Hook hook) {
+  WRing<D> r;
+  wring_prologue<NKK, NTO, D>(r, Wlane);
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) {
+    hook(kk);
+    __builtin_amdgcn_sched_barrier(0);
+    split_kstep_stream<KT, NKK, NTO, D>(r, Wlane, kk, B[kk], Y);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // fp32 register tile (NT_ feature tiles) -> NT_/2 k-steps of B fragments, optionally through GELU
 template <int NT_, int KT, bool GELU>
 __device__ __forceinline__ void tile_to_bfrag(const f32x4 (&V)[NT_][KT], BFrag (&B)[NT_ / 2][KT]) {

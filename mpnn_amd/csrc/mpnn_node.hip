@@ -25,9 +25,28 @@ constexpr int WSPLIT = MPNN_NT * NKK * 2 * 64;  // h8 elements of one packed 128
 #ifndef MPNN_NODE_LDS_RING
 #define MPNN_NODE_LDS_RING 6  // measured: 3 -> 0.335, 6 -> 0.309, 10 / 15 -> 0.309 ms per step (7 launches, B32 x L512)
 #endif
+#ifndef MPNN_NODE_DMA_SPREAD
+#define MPNN_NODE_DMA_SPREAD 1
+#endif
 #ifndef MPNN_NODE_WAVES
 #define MPNN_NODE_WAVES 4  // waves (16-node tiles) per workgroup of k_node_update
 #endif
+
+// quarter `part` (0 .. NKK-1) of a matrix' DMA: the GEMM of the stage before issues one quarter per k-step - sixteen
+// LDS-DMA loads back to back fill the address unit's queue and the wave waits at their issue (see mpnn_edge.hip)
+__device__ __forceinline__ void stage_matrix_part(const h8* __restrict__ g, h8* l, int part) {
+#ifdef MPNN_ABL_NODMA
+  return;
+#endif
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int PER = WSPLIT / (64 * MPNN_NODE_WAVES) / NKK;
+#pragma unroll
+  for (int i = part * PER; i < (part + 1) * PER; ++i) {
+    const int chunk = i * MPNN_NODE_WAVES + wave;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + chunk * 64 + lane),
+                                     (__attribute__((address_space(3))) void*)(l + chunk * 64), 16, 0, 0);
+  }
+}
 
 __device__ __forceinline__ void stage_matrix(const h8* __restrict__ g, h8* l) {
 #ifdef MPNN_ABL_NODMA  // timing-only ablation build: never shipped
@@ -45,14 +64,39 @@ __device__ __forceinline__ void stage_matrix(const h8* __restrict__ g, h8* l) {
 __global__ void __launch_bounds__(64 * MPNN_NODE_WAVES)
 k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, const float* __restrict__ cnt,
               float cnt_const, const float* __restrict__ mask, const h8* __restrict__ W3,
-              const float* __restrict__ b3, const float* __restrict__ ln1w, const float* __restrict__ ln1b,
-              const h8* __restrict__ Win, const float* __restrict__ bin, const h8* __restrict__ Wout,
-              const float* __restrict__ bout, const float* __restrict__ ln2w, const float* __restrict__ ln2b,
-              float inv_scale, int do_update, const h8* __restrict__ Wproj, const float* __restrict__ bproj,
+              const float* __restrict__ b3_g, const float* __restrict__ ln1w_g, const float* __restrict__ ln1b_g,
+              const h8* __restrict__ Win, const float* __restrict__ bin_g, const h8* __restrict__ Wout,
+              const float* __restrict__ bout_g, const float* __restrict__ ln2w_g, const float* __restrict__ ln2b_g,
+              float inv_scale, int do_update, const h8* __restrict__ Wproj, const float* __restrict__ bproj_g,
               int nproj, const float* __restrict__ add_table, int ld_table, int off_table,
               const long long* __restrict__ add_idx, int add_block, int N, float* __restrict__ hV_out,
               float* __restrict__ PQ, const int* __restrict__ node_list) {
   __shared__ h8 lds[2 * WSPLIT];
+  // every bias / LayerNorm vector of the launch, copied to LDS once: with one wave per SIMD each of their reads from
+  // global memory was an exposed L2 round trip per stage (phase stamps: a third of the kernel outside its GEMMs)
+  constexpr int PRM_PROJ = 7 * MPNN_H + 4 * MPNN_H;  // b3 ln1w ln1b | bin (512) | bout ln2w ln2b | bproj (<= 8 blocks)
+  __shared__ __align__(16) float prm[PRM_PROJ + 8 * MPNN_H];
+  {
+    const int t = threadIdx.x;
+    for (int i = t; i < MPNN_H; i += blockDim.x) {
+      if (do_update == 1) {
+        prm[i] = b3_g[i]; prm[MPNN_H + i] = ln1w_g[i]; prm[2 * MPNN_H + i] = ln1b_g[i];
+        prm[8 * MPNN_H + i] = ln2w_g[i]; prm[9 * MPNN_H + i] = ln2b_g[i];
+      }
+      if (do_update) prm[7 * MPNN_H + i] = bout_g[i];
+    }
+    if (do_update)
+      for (int i = t; i < 4 * MPNN_H; i += blockDim.x) prm[3 * MPNN_H + i] = bin_g[i];
+    for (int i = t; i < nproj * MPNN_H; i += blockDim.x) prm[PRM_PROJ + i] = bproj_g[i];
+  }
+  const float* b3 = prm;
+  const float* ln1w = prm + MPNN_H;
+  const float* ln1b = prm + 2 * MPNN_H;
+  const float* bin = prm + 3 * MPNN_H;
+  const float* bout = prm + 7 * MPNN_H;
+  const float* ln2w = prm + 8 * MPNN_H;
+  const float* ln2b = prm + 9 * MPNN_H;
+  const float* bproj = prm + PRM_PROJ;
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * MPNN_NODE_WAVES + (threadIdx.x >> 6);
   const int g = lane >> 4, col = lane & 15;
@@ -79,32 +123,44 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
   auto prefetch = [&]() {
     if (k + 1 < nmat) stage_matrix(matrix(k + 1), lds + ((k + 1) & 1) * WSPLIT);
   };
+#if MPNN_NODE_DMA_SPREAD
+  auto prefetch_part = [&](int part) {
+    if (k + 1 < nmat) stage_matrix_part(matrix(k + 1), lds + ((k + 1) & 1) * WSPLIT, part);
+  };
+#else
+  auto prefetch_part = [&](int part) {
+    if (part == 0) prefetch();
+  };
+#endif
   auto retire = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     ++k;
   };
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  f32x4 h[MPNN_NT][1];
+  // the tile's own rows are requested before the wait for the first matrix: they arrive with it
+  f32x4 h[MPNN_NT][1], gs[MPNN_NT][1];
+  float cn = cnt_const, mk = 1.0f;
 #pragma unroll
   for (int t = 0; t < MPNN_NT; ++t)
     h[t][0] = *reinterpret_cast<const f32x4*>(hV_in + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+  if (do_update == 1) {
+#pragma unroll
+    for (int t = 0; t < MPNN_NT; ++t)
+      gs[t][0] = *reinterpret_cast<const f32x4*>(gsum + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+    if (cnt) cn = cnt[nd];
+    mk = mask[nd];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
   if (do_update) {
     BFrag xb[NKK][1];
     if (do_update == 1) {
-      f32x4 gs[MPNN_NT][1], dh[MPNN_NT][1];
-      const float cn = cnt ? cnt[nd] : cnt_const;
+      f32x4 dh[MPNN_NT][1];
 #pragma unroll
-      for (int t = 0; t < MPNN_NT; ++t) {
-        gs[t][0] = *reinterpret_cast<const f32x4*>(gsum + (size_t)nd * MPNN_H + 16 * t + 4 * g);
-        dh[t][0] = *reinterpret_cast<const f32x4*>(b3 + 16 * t + 4 * g) * cn;
-      }
+      for (int t = 0; t < MPNN_NT; ++t) dh[t][0] = *reinterpret_cast<const f32x4*>(b3 + 16 * t + 4 * g) * cn;
       tile_to_bfrag<MPNN_NT, 1, false>(gs, xb);
-      prefetch();
-      split_gemm_stream<1, NKK, MPNN_NT, MPNN_NODE_LDS_RING>(lds + (k & 1) * WSPLIT + lane, xb, dh);
+      split_gemm_stream_hook<1, NKK, MPNN_NT, MPNN_NODE_LDS_RING>(lds + (k & 1) * WSPLIT + lane, xb, dh, prefetch_part);
       retire();
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t) h[t][0] = h[t][0] + dh[t][0] * inv_scale;
@@ -123,20 +179,14 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t)
         hid[t][0] = *reinterpret_cast<const f32x4*>(bin + 128 * q + 16 * t + 4 * g);
-      prefetch();
-      split_gemm_stream<1, NKK, MPNN_NT, MPNN_NODE_LDS_RING>(lds + (k & 1) * WSPLIT + lane, xb, hid);
+      split_gemm_stream_hook<1, NKK, MPNN_NT, MPNN_NODE_LDS_RING>(lds + (k & 1) * WSPLIT + lane, xb, hid, prefetch_part);
       retire();
       BFrag hb[NKK][1];
       tile_to_bfrag<MPNN_NT, 1, true>(hid, hb);
-      prefetch();
-      split_gemm_stream<1, NKK, MPNN_NT, MPNN_NODE_LDS_RING>(lds + (k & 1) * WSPLIT + lane, hb, o);
+      split_gemm_stream_hook<1, NKK, MPNN_NT, MPNN_NODE_LDS_RING>(lds + (k & 1) * WSPLIT + lane, hb, o, prefetch_part);
       retire();
     }
-    float mk = 1.0f;
-    if (do_update == 1) {
-      tile_layernorm<1>(o, ln2w, ln2b, lane);
-      mk = mask[nd];
-    }
+    if (do_update == 1) tile_layernorm<1>(o, ln2w, ln2b, lane);
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
       h[t][0] = o[t][0] * mk;
@@ -150,8 +200,7 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
     f32x4 y[MPNN_NT][1];
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) y[t][0] = *reinterpret_cast<const f32x4*>(bproj + p * MPNN_H + 16 * t + 4 * g);
-    prefetch();
-    split_gemm_stream<1, NKK, MPNN_NT, MPNN_NODE_LDS_RING>(lds + (k & 1) * WSPLIT + lane, pb, y);
+    split_gemm_stream_hook<1, NKK, MPNN_NT, MPNN_NODE_LDS_RING>(lds + (k & 1) * WSPLIT + lane, pb, y, prefetch_part);
     retire();
     if (add_table && p == add_block) {  // decoder: fold the sequence term W1c W_s[S_n] into the A block
       const float* tr = add_table + (size_t)add_idx[nd] * ld_table + off_table + 4 * g;
@@ -387,7 +436,8 @@ extern "C" int MPNN_API(mpnn_node_update)(const float* hV_in, const float* gsum,
                                 float scale, int do_update, const float* Wproj_packed, const float* bproj, int nproj,
                                 const float* add_table, int ld_table, int off_table, const int64_t* add_idx,
                                 int add_block, int n_nodes, float* hV_out, float* PQ, void* stream) {
-  MPNN_CHECK_ARG(hV_in && n_nodes > 0 && nproj >= 0 && do_update >= 0 && do_update <= 2, "mpnn_node_update: bad arguments");
+  MPNN_CHECK_ARG(hV_in && n_nodes > 0 && nproj >= 0 && nproj <= 8 && do_update >= 0 && do_update <= 2,
+                 "mpnn_node_update: bad arguments (at most 8 projection blocks)");
   if (do_update == 2)
     MPNN_CHECK_ARG(Win_packed && b_in && Wout_packed && b_out && hV_out, "mpnn_node_update: null pointer in the FFN-only form");
   if (do_update == 1)
