@@ -1073,7 +1073,9 @@ level_node(h8* lds, float (*gsl)[MPNN_H], const W3Frags& w3, const int* __restri
   const int nd = node_list[live ? idx : n_list - 1];
   f32x4 h[MPNN_NT][1], o[MPNN_NT][1];
   BFrag xb[NKK][1];
+  float mk = 1.0f;
   if (act) {
+    mk = mask[nd];  // requested with the rows: at its point of use it was one more round trip on the chain
     f32x4 gs[MPNN_NT][1];
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
@@ -1116,7 +1118,6 @@ level_node(h8* lds, float (*gsl)[MPNN_H], const W3Frags& w3, const int* __restri
       o[t][0] = h[t][0] + *reinterpret_cast<const f32x4*>(bout + 16 * t + 4 * g) + sum;
     }
     tile_layernorm<1>(o, ln2w, ln2b, lane);
-    const float mk = mask[nd];
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
       h[t][0] = o[t][0] * mk;
@@ -1154,6 +1155,10 @@ k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, 
                   float* __restrict__ hV_out, float* __restrict__ PQ, int lvn) {
   __shared__ h8 lds[2 * WSPLIT];
   __shared__ float gsl[16][MPNN_H];
+  // the node phase's bias / LayerNorm vectors, copied to LDS while the message phase runs: read from global memory at
+  // their point of use each was one more exposed round trip on the level's dependency chain
+  constexpr int LPRM_PROJ = 10 * MPNN_H, LPRM_MAXPROJ = 8;  // the launcher checks nproj <= 8
+  __shared__ __align__(16) float lprm[LPRM_PROJ + LPRM_MAXPROJ * MPNN_H];
   const int tile = blockIdx.x;
   const int nlive = min(lvn, n_list - tile * lvn);
   // MPNN_ABL_LEVEL_*: timing-only ablation builds (never shipped): what each phase of a level costs
@@ -1161,6 +1166,27 @@ k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, 
   lds_fill_issue(f1, W1b);
   lds_fill_issue(f2, W2);
   for (int i = threadIdx.x; i < 16 * MPNN_H; i += blockDim.x) (&gsl[0][0])[i] = 0.f;
+  {
+    float pv[3];
+    const int t = threadIdx.x;  // 768 threads: at most three floats each
+    const int nprm = LPRM_PROJ + nproj * MPNN_H;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = t + u * (MPNN_MSGT_WAVES * 64);
+      pv[u] = 0.f;
+      if (i < nprm) {
+        const int blk = i >> 7, j = i & 127;
+        const float* src = blk == 0 ? b3 : blk == 1 ? ln1w : blk == 2 ? ln1b : blk < 7 ? bin + 128 * (blk - 3)
+                         : blk == 7 ? bout : blk == 8 ? ln2w : blk == 9 ? ln2b : bproj + 128 * (blk - 10);
+        pv[u] = src[j];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = t + u * (MPNN_MSGT_WAVES * 64);
+      if (i < nprm) lprm[i] = pv[u];
+    }
+  }
   LevelItem it;
   level_item_setup(it, hE, rank, E_idx, mask, edge_mask, node_list, tile, lvn, nlive, enc_mod, L, K, KT);
   f32x4 xt[MPNN_NT], h1[MPNN_NT][1];
@@ -1179,8 +1205,9 @@ k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, 
 #endif
   __syncthreads();  // neighbour sums complete; the message weights in LDS are dead from here on
 #ifndef MPNN_ABL_LEVEL_NONODE
-  level_node(lds, gsl, w3, node_list, n_list, tile, lvn, mask, hV_in, cnt_const, b3, ln1w, ln1b, Win, bin, Wout, bout, ln2w,
-             ln2b, inv_scale, Wproj, bproj, nproj, hV_out, PQ);
+  level_node(lds, gsl, w3, node_list, n_list, tile, lvn, mask, hV_in, cnt_const, lprm, lprm + MPNN_H, lprm + 2 * MPNN_H, Win,
+             lprm + 3 * MPNN_H, Wout, lprm + 7 * MPNN_H, lprm + 8 * MPNN_H, lprm + 9 * MPNN_H, inv_scale, Wproj,
+             lprm + LPRM_PROJ, nproj, hV_out, PQ);
 #else
   if (w3.hi[0][0] == (_Float16)77.f && gsl[1][1] == 5.f) hV_out[0] = 1.f;
 #endif
@@ -1600,9 +1627,9 @@ extern "C" int MPNN_API(mpnn_dec_layer_subset)(const float* hE_frag, const float
                      b_out && ln2_w && ln2_b && hV_out,
                  "mpnn_dec_layer_subset: null pointer");
   MPNN_CHECK_ARG(n_list > 0 && L > 0 && enc_nodes > 0 && enc_nodes % L == 0 && K >= 1 && K <= 48 && scale != 0.f &&
-                     nproj >= 0 && (nproj == 0 || (Wproj_packed && bproj && PQ)) &&
+                     nproj >= 0 && nproj <= 8 && (nproj == 0 || (Wproj_packed && bproj && PQ)) &&
                      mult4(ldp, offP, lda, offA, ldenc, offEnc),
-                 "mpnn_dec_layer_subset: bad sizes (K <= 48; strides/offsets multiples of 4 floats)");
+                 "mpnn_dec_layer_subset: bad sizes (K <= 48; at most 8 projection blocks; strides/offsets multiples of 4 floats)");
   const int KT = (K + 15) / 16;
   const int lvn = level_nodes_per_wg(n_list);
   hipLaunchKernelGGL(k_dec_layer_level, dim3(ceil_div(n_list, lvn)), dim3(MPNN_MSGT_WAVES * 64), 0, (hipStream_t)stream,
