@@ -239,13 +239,30 @@ struct DropCfg {
 __global__ void __launch_bounds__(256)
 k_node_update_train(const float* __restrict__ hV_in, const float* __restrict__ gsum, const float* __restrict__ cnt,
                     float cnt_const, const float* __restrict__ mask, const h8* __restrict__ W3,
-                    const float* __restrict__ b3, const float* __restrict__ ln1w, const float* __restrict__ ln1b,
-                    const h8* __restrict__ Win, const float* __restrict__ bin, const h8* __restrict__ Wout,
-                    const float* __restrict__ bout, const float* __restrict__ ln2w, const float* __restrict__ ln2b,
-                    float inv_scale, const h8* __restrict__ Wproj, const float* __restrict__ bproj, int nproj, int N,
+                    const float* __restrict__ b3_g, const float* __restrict__ ln1w_g, const float* __restrict__ ln1b_g,
+                    const h8* __restrict__ Win, const float* __restrict__ bin_g, const h8* __restrict__ Wout,
+                    const float* __restrict__ bout_g, const float* __restrict__ ln2w_g, const float* __restrict__ ln2b_g,
+                    float inv_scale, const h8* __restrict__ Wproj, const float* __restrict__ bproj_g, int nproj, int N,
                     float* __restrict__ hV_out, float* __restrict__ PQ, float* __restrict__ s_x1pre,
                     float* __restrict__ s_a, float* __restrict__ s_x2pre, DropCfg dc) {
   __shared__ h8 lds[2 * WSPLIT_N];
+  // bias / LayerNorm vectors in LDS, copied once (as in k_node_update: their per-stage global reads were exposed)
+  constexpr int PRM_PROJ = 11 * MPNN_H;  // b3 ln1w ln1b | bin (512) | bout ln2w ln2b | bproj (<= 8 blocks)
+  __shared__ __align__(16) float prm[PRM_PROJ + 8 * MPNN_H];
+  for (int i = threadIdx.x; i < MPNN_H; i += blockDim.x) {
+    prm[i] = b3_g[i]; prm[MPNN_H + i] = ln1w_g[i]; prm[2 * MPNN_H + i] = ln1b_g[i];
+    prm[7 * MPNN_H + i] = bout_g[i]; prm[8 * MPNN_H + i] = ln2w_g[i]; prm[9 * MPNN_H + i] = ln2b_g[i];
+  }
+  for (int i = threadIdx.x; i < 4 * MPNN_H; i += blockDim.x) prm[3 * MPNN_H + i] = bin_g[i];
+  for (int i = threadIdx.x; i < nproj * MPNN_H; i += blockDim.x) prm[PRM_PROJ + i] = bproj_g[i];
+  const float* b3 = prm;
+  const float* ln1w = prm + MPNN_H;
+  const float* ln1b = prm + 2 * MPNN_H;
+  const float* bin = prm + 3 * MPNN_H;
+  const float* bout = prm + 7 * MPNN_H;
+  const float* ln2w = prm + 8 * MPNN_H;
+  const float* ln2b = prm + 9 * MPNN_H;
+  const float* bproj = prm + PRM_PROJ;
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int g = lane >> 4, col = lane & 15;
@@ -573,7 +590,8 @@ extern "C" int mpnn_node_update_train(const float* hV_in, const float* gsum, con
   MPNN_CHECK_ARG(hV_in && gsum && mask && W3_packed && b3 && ln1_w && ln1_b && Win_packed && b_in && Wout_packed &&
                      b_out && ln2_w && ln2_b && hV_out && x1pre && a_pre && x2pre && n_nodes > 0 && nproj >= 0,
                  "mpnn_node_update_train: bad arguments");
-  MPNN_CHECK_ARG(nproj == 0 || (Wproj_packed && bproj && PQ_blocks), "mpnn_node_update_train: projections need Wproj, bproj, PQ");
+  MPNN_CHECK_ARG(nproj >= 0 && nproj <= 8 && (nproj == 0 || (Wproj_packed && bproj && PQ_blocks)),
+                 "mpnn_node_update_train: projections need Wproj, bproj, PQ (at most 8 blocks)");
   MPNN_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mpnn_node_update_train: dropout probability must be in [0, 1)");
   hipLaunchKernelGGL(k_node_update_train, dim3((n_nodes + 63) / 64), dim3(256), 0, (hipStream_t)stream, hV_in, gsum, cnt,
                      cnt_const, mask, (const h8*)W3_packed, b3, ln1_w, ln1_b, (const h8*)Win_packed, b_in,
