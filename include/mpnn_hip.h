@@ -265,7 +265,8 @@ int mpnn_logits_log_softmax(const float* hV, const float* Wout_packed, const flo
  * Training step: per-edge kernels with saved pre-activations and their backward.  The reference differentiates
  * EncLayer.forward (:73-95) / DecLayer.forward (:118-138) with torch autograd inside train.py:375-392; here the
  * same gradients come from explicit kernels.  All *_frag arrays use hE's fragment layout; P / Row* / dP / out*
- * are dense [n_nodes,128]; *_rows are row-major [n_nodes * 16 ceil(K/16)][128].  K <= 48.
+ * are dense [n_nodes,128]; *_rows are row-major [n_nodes * 16 ceil(K/16)][128].  K <= 64 (K > 48 runs the
+ * four-column-tile instances: correct, register-spilling, untuned).
  * ------------------------------------------------------------------------------------------------------------ */
 
 /* Forward of mpnn_enc_message (dec = 0: Row = RowA[j], cnt written) or mpnn_dec_message (dec = 1: Row = RowA[j]

@@ -1537,7 +1537,7 @@ extern "C" int MPNN_API(mpnn_decode_level)(const float* hE_frag, const float* PV
   MPNN_LAUNCH_CHECK();
 }
 
-// ---- training forward: same kernels, pre-activations saved for mpnn_edge_bwd.hip (K <= 48) ----
+// ---- training forward: same kernels, pre-activations saved for mpnn_edge_bwd.hip (K <= 64) ----
 #ifndef MPNN_FAST
 extern "C" int mpnn_message_train(int dec, const float* hE_frag, const float* P, const float* RowA, const float* RowB,
                                   const int32_t* rank, const int32_t* E_idx32, const float* mask,
@@ -1547,7 +1547,7 @@ extern "C" int mpnn_message_train(int dec, const float* hE_frag, const float* P,
   MPNN_CHECK_ARG(hE_frag && P && RowA && E_idx32 && mask && W1b_packed && W2_packed && b2 && gsum && a1_frag && a2_frag,
                  "mpnn_message_train: null pointer");
   MPNN_CHECK_ARG(dec ? (RowB && rank) : (cnt != nullptr), "mpnn_message_train: decoder needs RowB and rank, encoder cnt");
-  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 48, "mpnn_message_train: bad sizes (training path covers K <= 48)");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64, "mpnn_message_train: bad sizes (K <= 64)");
   const int N = B * L, KT = (K + 15) / 16;
   dim3 grid(edge_grid(N, MPNN_MSG_WAVES)), block(MPNN_MSG_WAVES * 64);
   if (dec) {
@@ -1575,8 +1575,8 @@ extern "C" int mpnn_enc_edge_update_train(const float* hE_frag, const float* P, 
   MPNN_CHECK_ARG(hE_frag && P && Q && E_idx32 && W11b_packed && W12_packed && b12 && W13_packed && b13 && ln_w &&
                      ln_b && hE_out && a1_frag && a2_frag && z_frag,
                  "mpnn_enc_edge_update_train: null pointer");
-  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 48 && hE_out != hE_frag,
-                 "mpnn_enc_edge_update_train: bad sizes (training path covers K <= 48, out of place)");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && hE_out != hE_frag,
+                 "mpnn_enc_edge_update_train: bad sizes (K <= 64, out of place)");
   MPNN_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mpnn_enc_edge_update_train: dropout probability must be in [0, 1)");
   const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
   const int N = B * L, KT = (K + 15) / 16;
@@ -1600,9 +1600,9 @@ extern "C" int MPNN_API(mpnn_dec_message_subset)(const float* hE_frag, const flo
   MPNN_CHECK_ARG(hE_frag && P && RowA && PVenc && rank && E_idx32 && mask && W1b_packed && W2_packed && b2 &&
                      node_list && gsum,
                  "mpnn_dec_message_subset: null pointer");
-  MPNN_CHECK_ARG(n_list > 0 && L > 0 && enc_nodes > 0 && enc_nodes % L == 0 && K >= 1 && K <= 48 &&
+  MPNN_CHECK_ARG(n_list > 0 && L > 0 && enc_nodes > 0 && enc_nodes % L == 0 && K >= 1 && K <= 64 &&
                      mult4(ldp, offP, lda, offA, ldenc, offEnc),
-                 "mpnn_dec_message_subset: bad sizes (K <= 48; strides/offsets multiples of 4 floats)");
+                 "mpnn_dec_message_subset: bad sizes (K <= 64; strides/offsets multiples of 4 floats)");
   const int KT = (K + 15) / 16;
   dim3 grid(edge_grid(n_list * KT, MPNN_MSGT_WAVES)), block(MPNN_MSGT_WAVES * 64);
   hipLaunchKernelGGL(k_message_level, grid, block, 0, (hipStream_t)stream, (const f32x4*)hE_frag, P, ldp, offP, RowA, lda,

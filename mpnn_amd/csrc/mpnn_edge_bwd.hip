@@ -372,7 +372,8 @@ k_features_bwd(const f32x4* __restrict__ dy, const f32x4* __restrict__ E0, const
 // ---------------------------------------------------------------------------
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 constexpr int WG_PART = MPNN_H * MPNN_H + MPNN_H;  // floats of one workgroup partial (dW | dbias)
-constexpr int WG_LDK = 52;  // padded edge stride (halves): 104-byte rows spread the 8-byte operand reads over banks
+// padded edge stride (halves) of the LDS planes: 16 KTM + 4 (104-byte rows at KTM = 3 spread the 8-byte operand reads over
+// banks); KTM = 3 for K <= 48 (three workgroups per CU), 4 for K <= 64 (one)
 
 // 4x4 transpose across a lane quad: out[j] of quad lane i = in[i] of quad lane j (two DPP exchange stages)
 __device__ __forceinline__ f32x4 quad_transpose(f32x4 v) {
@@ -402,10 +403,11 @@ __device__ __forceinline__ f32x4 quad_transpose(f32x4 v) {
 #ifndef MPNN_WGRAD_CONTIG
 #define MPNN_WGRAD_CONTIG 0  // 1: a workgroup walks a contiguous range of residues instead of a grid stride
 #endif
-template <bool A_NAT, bool B_GELU>
+template <bool A_NAT, bool B_GELU, int KTM>
 __global__ void __launch_bounds__(256)
 k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigned* __restrict__ amax, int N, int KT,
         float* __restrict__ part) {
+  constexpr int WG_LDK = 16 * KTM + 4;
   __shared__ _Float16 sA[2][MPNN_H][WG_LDK];
   __shared__ _Float16 sB[2][MPNN_H][WG_LDK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -420,13 +422,13 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
   const f32x4* Af = reinterpret_cast<const f32x4*>(A);
   const float sc = pow2_scale_from_bits(*amax), un = pow2_inverse(sc);  // see grad_to_bfrag
   // this thread's share of a residue: feature tiles t = 2 wave + {0, 1}, every column tile (<= 3)
-  f32x4 va[2][3], vb[2][3];
+  f32x4 va[2][KTM], vb[2][KTM];
   auto fetch = [&](int node) {
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       const int t = 2 * wave + tt;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
+      for (int c = 0; c < KTM; ++c) {
         if (c < KT) {
           if (A_NAT)
             va[tt][c] = WGRAD_LOAD(
@@ -452,7 +454,7 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
+      for (int c = 0; c < KTM; ++c)
         if (c < KT) acc[tt][c] += va[tt][c] * vb[tt][c];
     if (node + nstep < Nend) fetch(node + nstep);
     continue;
@@ -462,7 +464,7 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
     for (int tt = 0; tt < 2; ++tt) {
       const int t = 2 * wave + tt;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
+      for (int c = 0; c < KTM; ++c) {
         if (c < KT) {
           f32x4 a = va[tt][c], b = vb[tt][c];
           if (B_GELU) b = gelu4(b);
@@ -620,18 +622,18 @@ extern "C" int mpnn_message_bwd(int dec, const float* dgsum, const float* a1_fra
   MPNN_CHECK_ARG(dgsum && a1_frag && a2_frag && E_idx32 && mask && W2T_packed && W1bT_packed && da2_frag &&
                      da1_rows && dP && dE_frag && amax2,
                  "mpnn_message_bwd: null pointer");
-  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 48, "mpnn_message_bwd: bad sizes (training path covers K <= 48)");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64, "mpnn_message_bwd: bad sizes (K <= 64)");
   const int N = B * L, KT = (K + 15) / 16;
   dim3 grid(edge_grid(N, MPNN_BWD_WAVES)), block(MPNN_BWD_WAVES * 64);
   if (dec) {
-    KT_DISPATCH(KT > 3 ? 3 : KT,
-                hipLaunchKernelGGL((k_message_bwd<(kKT > 3 ? 3 : kKT), true>), grid, block, 0, (hipStream_t)stream, dgsum,
+    KT_DISPATCH(KT,
+                hipLaunchKernelGGL((k_message_bwd<kKT, true>), grid, block, 0, (hipStream_t)stream, dgsum,
                                    (const f32x4*)a1_frag, (const f32x4*)a2_frag, E_idx32, mask, edge_mask,
                                    (const h8*)W2T_packed, (const h8*)W1bT_packed, N, L, K, (f32x4*)da2_frag, da1_rows,
                                    dP, (f32x4*)dE_frag, accumulate, (unsigned*)amax2));
   } else {
-    KT_DISPATCH(KT > 3 ? 3 : KT,
-                hipLaunchKernelGGL((k_message_bwd<(kKT > 3 ? 3 : kKT), false>), grid, block, 0, (hipStream_t)stream,
+    KT_DISPATCH(KT,
+                hipLaunchKernelGGL((k_message_bwd<kKT, false>), grid, block, 0, (hipStream_t)stream,
                                    dgsum, (const f32x4*)a1_frag, (const f32x4*)a2_frag, E_idx32, mask, edge_mask,
                                    (const h8*)W2T_packed, (const h8*)W1bT_packed, N, L, K, (f32x4*)da2_frag, da1_rows,
                                    dP, (f32x4*)dE_frag, accumulate, (unsigned*)amax2));
@@ -647,14 +649,13 @@ extern "C" int mpnn_enc_edge_update_bwd(const float* dy_frag, const float* z_fra
   MPNN_CHECK_ARG(dy_frag && z_frag && a2_frag && a1_frag && ln_w && W13T_packed && W12T_packed && W11bT_packed &&
                      dz_frag && da2_frag && da1_rows && dP && dE_frag && dln && amax3,
                  "mpnn_enc_edge_update_bwd: null pointer");
-  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 48,
-                 "mpnn_enc_edge_update_bwd: bad sizes (training path covers K <= 48)");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64, "mpnn_enc_edge_update_bwd: bad sizes (K <= 64)");
   MPNN_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mpnn_enc_edge_update_bwd: dropout probability must be in [0, 1)");
   const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
   const int N = B * L, KT = (K + 15) / 16;
   dim3 grid(edge_grid(N, MPNN_BWD_WAVES)), block(MPNN_BWD_WAVES * 64);
-  KT_DISPATCH(KT > 3 ? 3 : KT,
-              hipLaunchKernelGGL((k_edge_update_bwd<(kKT > 3 ? 3 : kKT)>), grid, block, 0, (hipStream_t)stream,
+  KT_DISPATCH(KT,
+              hipLaunchKernelGGL((k_edge_update_bwd<kKT>), grid, block, 0, (hipStream_t)stream,
                                  (const f32x4*)dy_frag, (const f32x4*)z_frag, (const f32x4*)a2_frag,
                                  (const f32x4*)a1_frag, ln_w, (const h8*)W13T_packed, (const h8*)W12T_packed,
                                  (const h8*)W11bT_packed, N, (f32x4*)dz_frag, (f32x4*)da2_frag, da1_rows, dP,
@@ -667,7 +668,7 @@ extern "C" int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax
                                int n_nodes, int K, float* dW, float* dbias, float* workspace, int workspace_floats,
                                void* stream) {
   MPNN_CHECK_ARG(A && A_absmax && B_frag && dW && workspace, "mpnn_edge_wgrad: null pointer");
-  MPNN_CHECK_ARG(n_nodes > 0 && K >= 1 && K <= 48, "mpnn_edge_wgrad: bad sizes (K <= 48)");
+  MPNN_CHECK_ARG(n_nodes > 0 && K >= 1 && K <= 64, "mpnn_edge_wgrad: bad sizes (K <= 64)");
   const int KT = (K + 15) / 16;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -675,20 +676,25 @@ extern "C" int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
   // three workgroups per CU (LDS 52 KiB, 166 registers each): the launch is bound by how many operand bytes are in flight
-  int nwg = n_nodes < MPNN_WGRAD_WG_PER_CU * cus ? n_nodes : MPNN_WGRAD_WG_PER_CU * cus;
+  const int per_cu = KT <= 3 ? MPNN_WGRAD_WG_PER_CU : 1;  // LDS: 53 KiB per workgroup at K <= 48, 70 KiB above
+  int nwg = n_nodes < per_cu * cus ? n_nodes : per_cu * cus;
   if (nwg > workspace_floats / WG_PART) nwg = workspace_floats / WG_PART;
   MPNN_CHECK_ARG(nwg >= 1, "mpnn_edge_wgrad: workspace holds no partial (needs >= 16512 floats, ideally 768 x 16512: mpnn_workspace_bytes)");
   dim3 grid(nwg), block(256);
   hipStream_t st = (hipStream_t)stream;
   const f32x4* Bf = (const f32x4*)B_frag;
   const unsigned* am = (const unsigned*)A_absmax;
+#define MPNN_WGRAD_LAUNCH(AN, BG)                                                                              \
+  do {                                                                                                         \
+    if (KT <= 3) hipLaunchKernelGGL((k_wgrad<AN, BG, 3>), grid, block, 0, st, A, Bf, am, n_nodes, KT, workspace); \
+    else hipLaunchKernelGGL((k_wgrad<AN, BG, 4>), grid, block, 0, st, A, Bf, am, n_nodes, KT, workspace);        \
+  } while (0)
   if (a_rows) {
-    if (b_gelu) hipLaunchKernelGGL((k_wgrad<true, true>), grid, block, 0, st, A, Bf, am, n_nodes, KT, workspace);
-    else hipLaunchKernelGGL((k_wgrad<true, false>), grid, block, 0, st, A, Bf, am, n_nodes, KT, workspace);
+    if (b_gelu) MPNN_WGRAD_LAUNCH(true, true); else MPNN_WGRAD_LAUNCH(true, false);
   } else {
-    if (b_gelu) hipLaunchKernelGGL((k_wgrad<false, true>), grid, block, 0, st, A, Bf, am, n_nodes, KT, workspace);
-    else hipLaunchKernelGGL((k_wgrad<false, false>), grid, block, 0, st, A, Bf, am, n_nodes, KT, workspace);
+    if (b_gelu) MPNN_WGRAD_LAUNCH(false, true); else MPNN_WGRAD_LAUNCH(false, false);
   }
+#undef MPNN_WGRAD_LAUNCH
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((WG_PART + 255) / 256, nwg < 16 ? nwg : 16), dim3(256), 0, st, workspace, nwg, dW,
                      dbias);
   MPNN_LAUNCH_CHECK();
@@ -709,11 +715,11 @@ extern "C" int mpnn_edge_features_bwd(const float* dhE_frag, const float* E0_fra
                                       float* amax2, void* stream) {
   MPNN_CHECK_ARG(dhE_frag && E0_frag && ln_w && WeT_packed && dE0_frag && dln && amax2,
                  "mpnn_edge_features_bwd: null pointer");
-  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 48, "mpnn_edge_features_bwd: bad sizes (K <= 48)");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64, "mpnn_edge_features_bwd: bad sizes (K <= 64)");
   const int N = B * L, KT = (K + 15) / 16;
   dim3 grid(edge_grid(N, MPNN_BWD_WAVES)), block(MPNN_BWD_WAVES * 64);
-  KT_DISPATCH(KT > 3 ? 3 : KT,
-              hipLaunchKernelGGL((k_features_bwd<(kKT > 3 ? 3 : kKT)>), grid, block, 0, (hipStream_t)stream,
+  KT_DISPATCH(KT,
+              hipLaunchKernelGGL((k_features_bwd<kKT>), grid, block, 0, (hipStream_t)stream,
                                  (const f32x4*)dhE_frag, (const f32x4*)E0_frag, ln_w, (const h8*)WeT_packed, N,
                                  (f32x4*)dE0_frag, dln, (unsigned*)amax2));
   MPNN_LAUNCH_CHECK();

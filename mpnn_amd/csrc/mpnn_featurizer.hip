@@ -946,7 +946,7 @@ extern "C" int mpnn_edge_features_train(const float* atoms, const int32_t* E_idx
   MPNN_CHECK_ARG(atoms && E_idx32 && residue_idx && chain_labels && pos_table && rbf_mu && Wemb_packed && ln_w &&
                      ln_b && We_packed && We_bias && hE_frag && E0_frag && E_frag,
                  "mpnn_edge_features_train: null pointer");
-  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 48, "mpnn_edge_features_train: need 1 <= K <= 48");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64, "mpnn_edge_features_train: need 1 <= K <= 64");
   MPNN_CHECK_ARG(n_atoms == 5 || n_atoms == 6, "mpnn_edge_features_train: n_atoms must be 5 or 6");
   const int KT = (K + 15) / 16, N = B * L;
   hipStream_t s = (hipStream_t)stream;
@@ -954,7 +954,8 @@ extern "C" int mpnn_edge_features_train(const float* atoms, const int32_t* E_idx
   switch (KT) {
     case 1: return launch_edge_features<1>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag);
     case 2: return launch_edge_features<2>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag);
-    default: return launch_edge_features<3>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag);
+    case 3: return launch_edge_features<3>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag);
+    default: return launch_edge_features<4>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag);
   }
 }
 #endif

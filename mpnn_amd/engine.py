@@ -710,8 +710,8 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
     with torch.no_grad():
         enc = _encode(model, X, mask, _i64(residue_idx), _i64(chain_encoding_all), backbone_noise)
         K = enc["K"]
-        if K > 48:
-            raise NotImplementedError("mpnn_amd.sample covers k_neighbors <= 48")
+        if K > 64:
+            raise NotImplementedError("mpnn_amd.sample covers k_neighbors <= 64")
         Ns = n_samples * N
         cm = (_f32(chain_M) * mask)
         if fix_order is not None:
@@ -774,8 +774,8 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
         # (mpnn_decode_level).  Both fused forms measured SLOWER on MI355X (one L = 512 sample: 6.7 ms / 7.3 ms /
         # 8.1 ms).  "split" = message / node update / head launches
         mode = os.environ.get("MPNN_SAMPLE_LAUNCHES", "layer")
-        if os.environ.get("MPNN_SAMPLE_UNFUSED") == "1":
-            mode = "split"
+        if os.environ.get("MPNN_SAMPLE_UNFUSED") == "1" or K > 48:
+            mode = "split"  # the fused level kernels give a workgroup four residues x three column tiles (K <= 48)
         f_layer = getattr(lib, _lib.entry("mpnn_dec_layer_subset"))
         f_msg = getattr(lib, _lib.entry("mpnn_dec_message_subset"))
         f_node = getattr(lib, _lib.entry("mpnn_node_update_subset"))

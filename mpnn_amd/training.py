@@ -497,9 +497,8 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
         atoms, _, E_idx64, E_idx32, _, edge_mask, K = engine._geometry(fm, X, mask, fix_backbone_noise, training)
         occ = engine._occupancy(fm, atoms, mask, B, L)
         g = Graph(E_idx64, E_idx32, mask.reshape(-1).contiguous(), edge_mask, K)
-    if K > 48:
-        raise NotImplementedError("mpnn_amd's differentiable path covers k_neighbors <= 48; for inference with more "
-                                  "neighbours call the model under torch.no_grad()")
+    if K > 64:
+        raise NotImplementedError("mpnn_amd covers k_neighbors <= 64")
     slot = GradSlot()
     hE = FeaturesFn.apply(g, slot, atoms, residue_idx, chain_labels, 6 if fm.use_virtual_center else 5,
                           fm.embeddings.linear.weight, fm.embeddings.linear.bias, fm.edge_embedding.weight,

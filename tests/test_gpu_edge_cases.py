@@ -144,11 +144,13 @@ def test_more_than_48_neighbours(kw, B, L):
     assert_close(out["log_probs"].cpu().numpy()[m], ref["log_probs"].numpy()[m], LP_RTOL, LP_ATOL, "log_probs")
     for got, want in zip(out["h_V_dec"], ref["h_V_dec"]):
         assert_close(got.cpu().numpy()[m], want.numpy()[m], 1e-4, 1e-5, "h_V_dec")
-    # the differentiable and sampling paths cover k <= 48 and say so
+    # the differentiable and the sampling path take the same neighbourhoods (gradients / contract checked in
+    # test_gpu_train.py::k64_L80 and test_gpu_sample.py::k64): here only that their log-probs agree with the forward
     d = {k: v.cuda() for k, v in b.items()}
     args = (d["X"], d["S"], d["mask"], d["chain_M"], d["residue_idx"], d["chain_encoding_all"])
-    with pytest.raises(NotImplementedError):
-        model(*args)                                   # grad mode on: differentiable path
-    with pytest.raises(NotImplementedError):
-        model.sample(d["X"], d["mask"], d["chain_M"], d["residue_idx"], d["chain_encoding_all"])
+    lp = model(*args, fix_order=d["fix_order"])        # grad mode on: differentiable path
+    assert lp.requires_grad
+    assert_close(lp.detach().cpu().numpy()[m], ref["log_probs"].numpy()[m], LP_RTOL, LP_ATOL, "log_probs (train path)")
+    out_s = model.sample(d["X"], d["mask"], d["chain_M"], d["residue_idx"], d["chain_encoding_all"], seed=5)
+    assert torch.isfinite(out_s["log_probs"]).all()
 

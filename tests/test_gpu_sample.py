@@ -23,6 +23,8 @@ CASES = {
                                                                    design_fraction=0.7), 3),
     "k30_cutoff": (dict(k_neighbors=30, edge_cutoff=14.0), dict(B=1, L=130, seed=8, n_chains=1, design_fraction=1.0), 4),
     "k16_short": (dict(k_neighbors=16), dict(B=3, L=40, seed=5, lengths=[40, 31, 12], n_chains=2, design_fraction=0.5), 2),
+    # four column tiles: message / node update / head launches per level (the fused level kernels stop at K = 48)
+    "k64": (dict(k_neighbors=64), dict(B=2, L=90, seed=13, lengths=[90, 75], n_chains=2, design_fraction=0.8), 2),
 }
 
 

@@ -72,6 +72,10 @@ CASES = {
     "k20_L40": (dict(k_neighbors=20), dict(B=3, L=40, seed=4, lengths=[40, 33, 17], n_chains=2, design_fraction=0.7)),
     "k30_cutoff_occ_vc": (dict(k_neighbors=30, edge_cutoff=12.0, occupancy_cutoff=10.0, use_virtual_center=True),
                           dict(B=2, L=72, seed=5, lengths=[72, 50], n_chains=3, design_fraction=0.6)),
+    # four column tiles: the K > 48 instances of the training kernels (streaming featurizer, KTM = 4 weight gradients)
+    "k64_L80": (dict(k_neighbors=64), dict(B=2, L=80, seed=11, lengths=[80, 70], n_chains=2, design_fraction=0.5)),
+    "k56_L96_vc": (dict(k_neighbors=56, use_virtual_center=True),
+                   dict(B=2, L=96, seed=12, lengths=[96, 61], n_chains=2, design_fraction=0.6)),
 }
 
 
