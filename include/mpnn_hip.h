@@ -118,7 +118,8 @@ int mpnn_order_masks(const int32_t* rank, const int64_t* E_idx64, const float* m
 /* EncLayer message (:75-81) with W1 split per input block and W3 hoisted:
  *   gsum[i] = sum_k m_ik gelu(W2 gelu(P_i + Q_{j(i,k)} + W1b e_ik) + b2),  cnt[i] = sum_k m_ik,
  *   m_ik = mask_i mask_j edge_mask_ik (:467-470).  P = W1a h + b1 and Q = W1c h are columns
- *   [offP, offP+128) / [offQ, offQ+128) of the node-projection buffer PQ (row stride ldpq). */
+ *   [offP, offP+128) / [offQ, offQ+128) of the node-projection buffer PQ (row stride ldpq; ldpq = 0: one row for
+ *   every node - before the first layer h_V = 0 (:448) and P | Q are the bias row, no projection launch needed). */
 int mpnn_enc_message(const float* hE_frag, const float* PQ, int ldpq, int offP, int offQ, const int32_t* E_idx32,
                      const float* mask, const float* edge_mask, const float* W1b_packed, const float* W2_packed,
                      const float* b2, int B, int L, int K, float* gsum, float* cnt, void* stream);

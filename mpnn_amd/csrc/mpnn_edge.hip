@@ -1370,7 +1370,8 @@ extern "C" int MPNN_API(mpnn_enc_message)(const float* hE_frag, const float* PQ,
                                 float* gsum, float* cnt, void* stream) {
   MPNN_CHECK_ARG(hE_frag && PQ && E_idx32 && mask && W1b_packed && W2_packed && b2 && gsum && cnt,
                  "mpnn_enc_message: null pointer");
-  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && ldpq >= 128 && mult4(ldpq, offP, offQ),
+  // ldpq == 0: ONE row serves every node (h_V = 0 before the first layer: P | Q are the bias row)
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && (ldpq >= 128 || ldpq == 0) && mult4(ldpq, offP, offQ),
                  "mpnn_enc_message: bad sizes (strides/offsets must be multiples of 4 floats)");
   const int N = B * L, KT = (K + 15) / 16;
 #ifdef MPNN_STAMP

@@ -448,10 +448,10 @@ def shared_structures(X, S, mask, residue_idx, chain_encoding_all):
 def _decoding_rank(chain_M, mask, fix_order, B, L):
     """decoding order [B, L] (given, or drawn as the reference does, :489-491) and its inverse permutation `rank`."""
     dev = mask.device
-    chain_M = _f32(chain_M) * mask
     if fix_order is not None:
         order = _i64(fix_order)
     else:  # the argsort of a [B, L] key is host-side plumbing
+        chain_M = _f32(chain_M) * mask
         order = torch.argsort((chain_M + 0.0001) * torch.abs(torch.randn(chain_M.shape, device=dev)))
     rank = torch.zeros(B * L, device=dev, dtype=torch.int32)
     call("mpnn_order_rank", ptr(order), B, L, ptr(rank), stream_ptr())
@@ -500,7 +500,8 @@ def _layers(pw, B, L, K, atoms, E_idx32, edge_mask, occ, mask, S, residue_idx, c
     hE, _ = _edge_features(pw, atoms, E_idx32, residue_idx, chain_labels, B, L, K, False)
 
     hV = torch.zeros(N, H, device=dev, dtype=torch.float32)
-    if pw.occ is not None and occ is not None:
+    has_occ = pw.occ is not None and occ is not None
+    if has_occ:
         o = pw.occ
         call("mpnn_occupancy_mlp", ptr(occ), ptr(o["w0"]), ptr(o["b0"]), ptr(o["W2"]), ptr(o["b2"]), ptr(o["lnw"]),
              ptr(o["lnb"]), N, ptr(hV), st)
@@ -519,13 +520,18 @@ def _layers(pw, B, L, K, atoms, E_idx32, edge_mask, occ, mask, S, residue_idx, c
     def dec_table(layer, block):  # adds TS_layer[S] to projection block `block` (the decoder's A rows)
         return (pw.TS, ldts, H * layer, S, block) if n_dec else None
 
-    PQ = new_pq(pw.g_init)
-    if pw.g_init[2]:
-        _node_update(hV, N, None, None, None, 0.0, None, pw.g_init, None, PQ,
-                     table=dec_table(0, 1) if (n_enc == 0 and n_dec) else None)
+    if n_enc and not has_occ:
+        # h_V = 0: every node's P | Q row of the first message kernel is the bias row (stride 0), no launch needed
+        PQ, ld = pw.g_init[1], 0
+    else:
+        PQ = new_pq(pw.g_init)
+        ld = PQ.shape[1] if PQ is not None else 0
+        if pw.g_init[2]:
+            _node_update(hV, N, None, None, None, 0.0, None, pw.g_init, None, PQ,
+                         table=dec_table(0, 1) if (n_enc == 0 and n_dec) else None)
 
     for l, lw in enumerate(pw.enc):
-        ld = PQ.shape[1]
+        ld = ld if l == 0 else PQ.shape[1]
         offP, offQ = (0, H) if l == 0 else (2 * H, 3 * H)
         call("mpnn_enc_message", ptr(hE), ptr(PQ), ld, offP, offQ, ptr(E_idx32), ptr(mask), ptr(edge_mask),
              ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"]), B, L, K, ptr(gsum), ptr(cnt), st)
@@ -649,12 +655,17 @@ def _encode(model, X, mask, residue_idx, chain_labels, backbone_noise):
     def new_pq(group):
         return torch.empty(N, max(group[2], 1) * H, device=dev, dtype=torch.float32) if group[2] else None
 
-    PQ = new_pq(pw.g_init)
-    if pw.g_init[2]:
-        _node_update(hV, N, None, None, None, 0.0, None, pw.g_init, None, PQ)
+    if pw.enc and not (pw.occ is not None and occ is not None):
+        PQ, ld = pw.g_init[1], 0   # h_V = 0: the bias row for every node (see _layers)
+    else:
+        PQ = new_pq(pw.g_init)
+        ld = PQ.shape[1] if PQ is not None else 0
+        if pw.g_init[2]:
+            _node_update(hV, N, None, None, None, 0.0, None, pw.g_init, None, PQ)
     for l, lw in enumerate(pw.enc):
+        ld = ld if l == 0 else PQ.shape[1]
         offP, offQ = (0, H) if l == 0 else (2 * H, 3 * H)
-        call("mpnn_enc_message", ptr(hE), ptr(PQ), PQ.shape[1], offP, offQ, ptr(E_idx32), ptr(mask), ptr(edge_mask),
+        call("mpnn_enc_message", ptr(hE), ptr(PQ), ld, offP, offQ, ptr(E_idx32), ptr(mask), ptr(edge_mask),
              ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"]), B, L, K, ptr(gsum), ptr(cnt), st)
         grp = pw.g_enc[l]
         PQn, hVn = new_pq(grp), torch.empty_like(hV)
