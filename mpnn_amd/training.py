@@ -504,7 +504,8 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
                           fm.embeddings.linear.weight, fm.embeddings.linear.bias, fm.edge_embedding.weight,
                           fm.norm_edges.weight, fm.norm_edges.bias, model.W_e.weight, model.W_e.bias)
     hV = torch.zeros(N, H, device=dev, dtype=torch.float32)
-    if model.occupancy_mlp is not None and occ is not None:
+    has_occ = model.occupancy_mlp is not None and occ is not None
+    if has_occ:
         hV = hV + model.occupancy_mlp(occ.view(N, 1))
     enc, dec = list(model.encoder_layers), list(model.decoder_layers)
     # every [128, 128 n] weight is cut into its column blocks ONCE (torch.split: one autograd node whose backward is a
@@ -521,8 +522,11 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
         return ([(W1s[id(dec[0])][0], dec[0].W1.bias), (W1s[id(dec[0])][3], None)] +
                 [(W1s[id(d_)][3], None) for d_ in dec])
 
-    first = msg_blocks(enc[0]) if enc else dec_first_blocks()
-    proj = [linear(hV, W, b) for W, b in first]
+    if enc and not has_occ:   # h_V = 0: P is the bias row, Q is zero (their weight blocks get zero gradients either way)
+        proj = [enc[0].W1.bias.float().expand(N, H), torch.zeros(N, H, device=dev, dtype=torch.float32)]
+    else:
+        first = msg_blocks(enc[0]) if enc else dec_first_blocks()
+        proj = [linear(hV, W, b) for W, b in first]
     for l, lyr in enumerate(enc):
         W1, W11 = W1s[id(lyr)], W11s[id(lyr)]
         gsum, cnt = MessageFn.apply(g, slot, False, hE, proj[0], proj[1], None, W1[1], lyr.W2.weight, lyr.W2.bias)
