@@ -308,7 +308,8 @@ int mpnn_enc_edge_update_bwd(const float* dy_frag, const float* z_frag, const fl
  * f = GELU when b_gelu != 0.  dW [128,128] row-major, accumulated with atomics (zero it first); dbias may be NULL.
  * A_absmax: device scalar >= max |A| (any positive value of that magnitude): gradients are tiny, so A is scaled by a
  * power of two derived from it before the f16 hi/lo split and the result scaled back.
- * workspace: device scratch for per-workgroup partial sums, 16512 floats per workgroup; 768 x 16512 floats lets the
+ * workspace: device scratch for per-workgroup partial sums, 16512 floats per workgroup; 2 x CUs x 16512 floats (what
+ * mpnn_workspace_bytes reports, with room to spare) lets the
  * launch fill the chip (fewer -> fewer workgroups). */
 int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax, const float* B_frag, int b_gelu, int n_nodes,
                     int K, float* dW, float* dbias, float* workspace, int workspace_floats, void* stream);

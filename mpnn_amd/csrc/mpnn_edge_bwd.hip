@@ -400,11 +400,26 @@ __device__ __forceinline__ f32x4 quad_transpose(f32x4 v) {
 #else
 #define WGRAD_LOAD(p) (*(p))
 #endif
+#ifndef MPNN_WGRAD_WAVES
+#define MPNN_WGRAD_WAVES 8  // waves per workgroup: 8 (one 16-row tile of dW per wave, ~100 registers, two workgroups =
+                            // 16 waves per CU) against 4 (two tiles, ~165 registers, three workgroups = 12 waves):
+                            // 3.39 against 3.71 ms per training step - the launch lives on loads in flight
+#endif
+#ifndef MPNN_WGRAD_WG_PER_CU
+#define MPNN_WGRAD_WG_PER_CU (MPNN_WGRAD_WAVES == 8 ? 2 : 3)
+#endif
+#ifndef MPNN_WGRAD_EARLY_FETCH
+#define MPNN_WGRAD_EARLY_FETCH 0  // 1: next residue's tiles requested as the conversion frees their registers (no gain)
+#endif
+#ifndef MPNN_WGRAD_X32
+#define MPNN_WGRAD_X32 0  // 1: full-depth MFMA form over pairs of column tiles - fewer MFMA cycles, but 12 more registers
+                          // (two waves per SIMD, or spills at three): 3.84 / 4.67 against 3.65 ms per step, not adopted
+#endif
 #ifndef MPNN_WGRAD_CONTIG
 #define MPNN_WGRAD_CONTIG 0  // 1: a workgroup walks a contiguous range of residues instead of a grid stride
 #endif
 template <bool A_NAT, bool B_GELU, int KTM>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * MPNN_WGRAD_WAVES, (MPNN_WGRAD_X32 && KTM <= 3) ? MPNN_WGRAD_WG_PER_CU : 1)
 k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigned* __restrict__ amax, int N, int KT,
         float* __restrict__ part) {
   constexpr int WG_LDK = 16 * KTM + 4;
@@ -413,32 +428,34 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, col = lane & 15;
   const int Kp = KT * 16;
-  f32x4 acc[2][MPNN_NT];
+  constexpr int TT = 8 / MPNN_WGRAD_WAVES;  // feature tiles (16 rows of dW) per wave
+  f32x4 acc[TT][MPNN_NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TT; ++i)
 #pragma unroll
     for (int j = 0; j < MPNN_NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 bacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 bacc[TT];
+#pragma unroll
+  for (int i = 0; i < TT; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const f32x4* Af = reinterpret_cast<const f32x4*>(A);
   const float sc = pow2_scale_from_bits(*amax), un = pow2_inverse(sc);  // see grad_to_bfrag
-  // this thread's share of a residue: feature tiles t = 2 wave + {0, 1}, every column tile (<= 3)
-  f32x4 va[2][KTM], vb[2][KTM];
+  // this thread's share of a residue: feature tiles t = TT wave + {0 .. TT-1}, every column tile
+  f32x4 va[TT][KTM], vb[TT][KTM];
+  auto fetch_one = [&](int node, int tt, int c) {
+    const int t = TT * wave + tt;
+    if (A_NAT)
+      va[tt][c] = WGRAD_LOAD(
+          reinterpret_cast<const f32x4*>(A + ((size_t)node * Kp + 16 * c + col) * MPNN_H + 16 * t + 4 * g));
+    else
+      va[tt][c] = WGRAD_LOAD(&Af[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane]);
+    vb[tt][c] = WGRAD_LOAD(&Bf[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane]);
+  };
   auto fetch = [&](int node) {
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int t = 2 * wave + tt;
+    for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-      for (int c = 0; c < KTM; ++c) {
-        if (c < KT) {
-          if (A_NAT)
-            va[tt][c] = WGRAD_LOAD(
-                reinterpret_cast<const f32x4*>(A + ((size_t)node * Kp + 16 * c + col) * MPNN_H + 16 * t + 4 * g));
-          else
-            va[tt][c] = WGRAD_LOAD(&Af[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane]);
-          vb[tt][c] = WGRAD_LOAD(&Bf[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane]);
-        }
-      }
-    }
+      for (int c = 0; c < KTM; ++c)
+        if (c < KT) fetch_one(node, tt, c);
   };
 #if MPNN_WGRAD_CONTIG
   const int per = (N + gridDim.x - 1) / gridDim.x;
@@ -452,7 +469,7 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
   for (; node < Nend; node += nstep) {
 #ifdef MPNN_ABL_WGRAD_STREAM  // timing-only ablation build (never shipped): the operand streams alone
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+    for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
       for (int c = 0; c < KTM; ++c)
         if (c < KT) acc[tt][c] += va[tt][c] * vb[tt][c];
@@ -461,12 +478,15 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
 #endif
     __syncthreads();  // previous residue's operand reads are done
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int t = 2 * wave + tt;
+    for (int tt = 0; tt < TT; ++tt) {
+      const int t = TT * wave + tt;
 #pragma unroll
       for (int c = 0; c < KTM; ++c) {
         if (c < KT) {
           f32x4 a = va[tt][c], b = vb[tt][c];
+#if MPNN_WGRAD_EARLY_FETCH
+          if (node + nstep < Nend) fetch_one(node + nstep, tt, c);  // the registers are free again: next residue's tile
+#endif
           if (B_GELU) b = gelu4(b);
           bacc[tt] += a;
           a *= sc;
@@ -491,48 +511,86 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
       }
     }
     __syncthreads();
+#if !MPNN_WGRAD_EARLY_FETCH
     if (node + nstep < Nend) fetch(node + nstep);  // next residue's loads fly under the MFMAs
-    for (int c = 0; c < KT; ++c) {
-      h4 ah[2], al[2];
+#endif
+#if MPNN_WGRAD_X32
+    // v_mfma_f32_16x16x16_f16 takes the same 16 cycles as the 16x16x32 form (tools/ubench/mfma_dep.hip): two column
+    // tiles (32 edges) go into ONE instruction - which edge sits at which k index is free as long as both operands
+    // agree, so the low half of a lane's 8 k values is its share of tile 2 cc and the high half that of tile 2 cc + 1
+    // (zeros when the neighbourhood has no such tile).  The LDS reads are those of the half-depth form.
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ah[i] = *reinterpret_cast<const h4*>(&sA[0][16 * (2 * wave + i) + col][16 * c + 4 * g]);
-        al[i] = *reinterpret_cast<const h4*>(&sA[1][16 * (2 * wave + i) + col][16 * c + 4 * g]);
+    for (int cc = 0; cc < (KTM + 1) / 2; ++cc) {
+      if (2 * cc < KT) {
+        constexpr h4 zero4 = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+        const bool two = 2 * cc + 1 < KTM && 2 * cc + 1 < KT;  // wave-uniform
+        auto pair = [&](const _Float16* row) {
+          const h4 lo = *reinterpret_cast<const h4*>(row + 32 * cc + 4 * g);
+          h4 hi = zero4;
+          if (2 * cc + 1 < KTM) {
+            hi = *reinterpret_cast<const h4*>(row + 32 * cc + 16 + 4 * g);
+            if (!two) hi = zero4;
+          }
+          return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        h8 ah[TT], al[TT];
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+          ah[i] = pair(&sA[0][16 * (TT * wave + i) + col][0]);
+          al[i] = pair(&sA[1][16 * (TT * wave + i) + col][0]);
+        }
+#pragma unroll
+        for (int j = 0; j < MPNN_NT; ++j) {
+          const h8 bh = pair(&sB[0][16 * j + col][0]);
+          const h8 bl = pair(&sB[1][16 * j + col][0]);
+#pragma unroll
+          for (int i = 0; i < TT; ++i) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+#else
+    for (int c = 0; c < KT; ++c) {
+      h4 ah[TT], al[TT];
+#pragma unroll
+      for (int i = 0; i < TT; ++i) {
+        ah[i] = *reinterpret_cast<const h4*>(&sA[0][16 * (TT * wave + i) + col][16 * c + 4 * g]);
+        al[i] = *reinterpret_cast<const h4*>(&sA[1][16 * (TT * wave + i) + col][16 * c + 4 * g]);
       }
 #pragma unroll
       for (int j = 0; j < MPNN_NT; ++j) {
         const h4 bh = *reinterpret_cast<const h4*>(&sB[0][16 * j + col][16 * c + 4 * g]);
         const h4 bl = *reinterpret_cast<const h4*>(&sB[1][16 * j + col][16 * c + 4 * g]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TT; ++i) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(al[i], bh, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[i], bl, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[i], bh, acc[i][j], 0, 0, 0);
         }
       }
     }
+#endif
   }
   // this workgroup's partial [128 x 128 | 128 bias sums] -> workspace (plain stores; k_wgrad_reduce adds them up:
   // 2^23 same-address-set atomics per launch from 512 workgroups cost more than the whole contraction)
   float* P = part + (size_t)blockIdx.x * WG_PART;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TT; ++i)
 #pragma unroll
     for (int j = 0; j < MPNN_NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) P[(16 * (2 * wave + i) + 4 * g + r) * MPNN_H + 16 * j + col] = acc[i][j][r] * un;
+      for (int r = 0; r < 4; ++r) P[(16 * (TT * wave + i) + 4 * g + r) * MPNN_H + 16 * j + col] = acc[i][j][r] * un;
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
+  for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float v = column_sum(bacc[tt][r]);
-      if (col == 0) P[MPNN_H * MPNN_H + 16 * (2 * wave + tt) + 4 * g + r] = v;
+      if (col == 0) P[MPNN_H * MPNN_H + 16 * (TT * wave + tt) + 4 * g + r] = v;
     }
 }
-
-#ifndef MPNN_WGRAD_WG_PER_CU
-#define MPNN_WGRAD_WG_PER_CU 3
-#endif
 
 // dW[i] += sum_w part[w][i]  (slice blockIdx.y of the partials; slices meet with one atomic per element)
 __global__ void __launch_bounds__(256)
@@ -675,12 +733,13 @@ extern "C" int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
-  // three workgroups per CU (LDS 52 KiB, 166 registers each): the launch is bound by how many operand bytes are in flight
-  const int per_cu = KT <= 3 ? MPNN_WGRAD_WG_PER_CU : 1;  // LDS: 53 KiB per workgroup at K <= 48, 70 KiB above
+  // as many waves per CU as LDS (53 KiB per workgroup at K <= 48, 70 KiB above) and registers allow: the launch is
+  // bound by how many operand bytes are in flight
+  const int per_cu = KT <= 3 ? MPNN_WGRAD_WG_PER_CU : (MPNN_WGRAD_WAVES == 8 ? 2 : 1);
   int nwg = n_nodes < per_cu * cus ? n_nodes : per_cu * cus;
   if (nwg > workspace_floats / WG_PART) nwg = workspace_floats / WG_PART;
-  MPNN_CHECK_ARG(nwg >= 1, "mpnn_edge_wgrad: workspace holds no partial (needs >= 16512 floats, ideally 768 x 16512: mpnn_workspace_bytes)");
-  dim3 grid(nwg), block(256);
+  MPNN_CHECK_ARG(nwg >= 1, "mpnn_edge_wgrad: workspace holds no partial (needs >= 16512 floats, ideally 2 per CU: mpnn_workspace_bytes)");
+  dim3 grid(nwg), block(64 * MPNN_WGRAD_WAVES);
   hipStream_t st = (hipStream_t)stream;
   const f32x4* Bf = (const f32x4*)B_frag;
   const unsigned* am = (const unsigned*)A_absmax;
