@@ -91,3 +91,38 @@ def test_positional_encodings_standalone():
         want = F.linear(F.one_hot(d, 66).float(), pe.linear.weight, pe.linear.bias)
         got = pe.cuda()(offset.cuda(), mask.cuda()).cpu()
     assert got.shape == want.shape and torch.allclose(got, want, rtol=0, atol=1e-6)
+
+
+def test_enc_message_one_row_for_every_node():
+    """mpnn_enc_message with ldpq = 0 (one P | Q row for every node: h_V = 0 before the first encoder layer,
+    model_utils.py:448, so the projections are the bias row) returns exactly what the materialised [N, 256] buffer
+    gives - the form the forward uses instead of a projection launch."""
+    from test_gpu_parity import build_model
+    from mpnn_amd import engine
+    from mpnn_amd._lib import call, ptr, stream_ptr
+    from mpnn_amd.synthetic import synthetic_batch
+
+    model = build_model(dict(k_neighbors=30))
+    b = {k: v.cuda() for k, v in synthetic_batch(B=2, L=70, seed=3, lengths=[70, 51], n_chains=2).items()}
+    pw, fm = engine.packed(model), model.features
+    mask = b["mask"].float().contiguous()
+    B, L = mask.shape
+    N, H = B * L, 128
+    atoms, _, _, E32, _, emask, K = engine._geometry(fm, b["X"], mask, None, False)
+    hE, _ = engine._edge_features(pw, atoms, E32, b["residue_idx"].long(), b["chain_encoding_all"].long(), B, L, K,
+                                  False)
+    lw, row = pw.enc[0], pw.g_init[1]
+    assert row.numel() == 2 * H and float(row[:H].abs().max()) > 0
+    outs = []
+    for PQ, ld in ((row.view(1, -1).repeat(N, 1).contiguous(), 2 * H), (row, 0)):
+        gsum = torch.full((N, H), float("nan"), device="cuda")
+        cnt = torch.full((N,), float("nan"), device="cuda")
+        call("mpnn_enc_message", ptr(hE), ptr(PQ), ld, 0, H, ptr(E32), ptr(mask), ptr(emask), ptr(lw["W1b"]),
+             ptr(lw["W2"]), ptr(lw["b2"]), B, L, K, ptr(gsum), ptr(cnt), stream_ptr())
+        torch.cuda.synchronize()
+        outs.append((gsum, cnt))
+    assert torch.isfinite(outs[0][0]).all() and float(outs[0][0].abs().max()) > 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    with pytest.raises(RuntimeError):   # any other stride below one row of P stays an error
+        call("mpnn_enc_message", ptr(hE), ptr(row), 64, 0, H, ptr(E32), ptr(mask), ptr(emask), ptr(lw["W1b"]),
+             ptr(lw["W2"]), ptr(lw["b2"]), B, L, K, ptr(outs[0][0]), ptr(outs[0][1]), stream_ptr())
