@@ -322,6 +322,19 @@ int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax, const flo
 int mpnn_gather_rows(const float* rows, const int32_t* inv_ptr, const int32_t* inv_row, const unsigned char* sel,
                      const int32_t* chunk_ptr, int n_nodes, int max_chunks, float* outA, float* outB, void* stream);
 
+/* Inverse neighbour lists for mpnn_gather_rows (the index side of the autograd of gather_nodes, :19-26, which the
+ * reference leaves to torch's scatter-add): inv_row [B*L*K] = edge ids (i * Kp + k, Kp = 16 ceil(K/16)) grouped by the
+ * node j = E_idx[i][k] they gather from and ordered by (i, k) inside a group - the order of a stable sort, the same
+ * on every run; inv_ptr [B*L + 1] the group offsets, chunk_ptr [B*L + 1] the offsets in chunks of <= 32 entries.
+ * E_idx32 [B*L, Kp] as mpnn_knn_topk writes it (ids local to the protein, a residue's K neighbours distinct).
+ * slot_map: B*L*L bytes of device scratch.  1 <= K <= min(64, L). */
+int mpnn_inverse_lists(const int32_t* E_idx32, int B, int L, int K, unsigned char* slot_map, int32_t* inv_ptr,
+                       int32_t* chunk_ptr, int32_t* inv_row, void* stream);
+/* sel [B*L*K] for mpnn_gather_rows in the decoder (:507-525): 1 where the gathering residue i does not come after its
+ * neighbour j in the decoding order (rank[i] <= rank[j]: the edge read the encoder block), in list order. */
+int mpnn_inverse_sel(const int32_t* rank, const int32_t* inv_ptr, const int32_t* inv_row, int n_nodes, int K,
+                     unsigned char* sel, void* stream);
+
 /* Training forward of mpnn_edge_features: also stores the pre-LayerNorm embedding E0 and E = norm_edges(E0), both in
  * the fragment layout, for mpnn_edge_features_bwd / mpnn_edge_wgrad (:334-358, :464). */
 int mpnn_edge_features_train(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,

@@ -63,6 +63,8 @@ SIGNATURES = {
     "mpnn_enc_edge_update_bwd": [_P] * 8 + [_I] * 3 + [_P] * 7 + [_F, ctypes.c_uint32, _P],
     "mpnn_edge_wgrad": [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P],
     "mpnn_gather_rows": [_P] * 5 + [_I, _I] + [_P] * 3,
+    "mpnn_inverse_lists": [_P, _I, _I, _I, _P, _P, _P, _P, _P],
+    "mpnn_inverse_sel": [_P, _P, _P, _I, _I, _P, _P],
     "mpnn_edge_features_train": [_P] * 11 + [_I, _I, _I, _I, _P, _P, _P, _P],
     "mpnn_edge_features_bwd": [_P] * 4 + [_I] * 3 + [_P] * 4,
     "mpnn_feature_chunks": [_P] * 5 + [_I] * 4 + [_P, _P],

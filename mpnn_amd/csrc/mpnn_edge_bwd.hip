@@ -759,6 +759,93 @@ extern "C" int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax
   MPNN_LAUNCH_CHECK();
 }
 
+// ---------------------------------------------------------------------------
+// Inverse neighbour lists for mpnn_gather_rows: for every node j the edges (i, k) with E_idx[i][k] = j, ordered by
+// (i, k) - what a stable sort of the edge list by its target gives (torch.argsort(stable=True): ~0.3 ms of merge-sort
+// and index launches per step).  A residue's K neighbours are distinct, so node j holds at most one edge of each
+// centre i of its protein: slot[j][i] (one byte, 0xFF = none) is a complete, collision-free map written with plain
+// byte stores, and reading row j in order of i yields the list already sorted - no atomics, no sort, the same result
+// on every run.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_inv_mark(const int* __restrict__ E, long long n_edges, int L, int K, int Kp, unsigned char* __restrict__ slot) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_edges) return;
+  const int p = (int)(e / K), k = (int)(e - (long long)p * K);
+  const int b = p / L;
+  const int j = E[(size_t)p * Kp + k];  // local to the protein
+  slot[((size_t)b * L + j) * L + (p - b * L)] = (unsigned char)k;
+}
+
+// FILL = false: deg[n] -> inv_ptr[n + 1];  FILL = true: the list of node n -> inv_row[inv_ptr[n] ...]
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+k_inv_rows(const unsigned char* __restrict__ slot, int N, int L, int Kp, int* __restrict__ inv_ptr,
+           int* __restrict__ inv_row) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const unsigned char* row = slot + (size_t)n * L;
+  const int first = (n / L) * L;  // first node of this protein
+  int base = FILL ? inv_ptr[n] : 0;
+  for (int p0 = 0; p0 < L; p0 += 64) {
+    const int p = p0 + lane;
+    const unsigned v = p < L ? row[p] : 0xFFu;
+    const unsigned long long m = __ballot(v != 0xFFu);
+    if (FILL && v != 0xFFu)
+      inv_row[base + __popcll(m & ((1ull << lane) - 1ull))] = (first + p) * Kp + (int)v;
+    base += __popcll(m);
+  }
+  if (!FILL && lane == 0) inv_ptr[n + 1] = base;
+}
+
+// one workgroup: inv_ptr[n + 1] holds deg[n] on entry and sum_{i <= n} deg[i] on exit (inv_ptr[0] = 0);
+// chunk_ptr likewise for ceil(deg / 32)
+__global__ void __launch_bounds__(1024)
+k_inv_scan(int N, int* __restrict__ inv_ptr, int* __restrict__ chunk_ptr) {
+  __shared__ int sd[1024], sc[1024];
+  const int t = threadIdx.x;
+  const int per = (N + 1023) / 1024;
+  const int n0 = min(N, t * per), n1 = min(N, n0 + per);
+  int d = 0, c = 0;
+  for (int n = n0; n < n1; ++n) {
+    const int deg = inv_ptr[n + 1];
+    d += deg;
+    c += (deg + GATHER_CHUNK - 1) / GATHER_CHUNK;
+  }
+  sd[t] = d;
+  sc[t] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan over the threads' sums
+    const int ad = t >= off ? sd[t - off] : 0, ac = t >= off ? sc[t - off] : 0;
+    __syncthreads();
+    sd[t] += ad;
+    sc[t] += ac;
+    __syncthreads();
+  }
+  int rd = sd[t] - d, rc = sc[t] - c;  // exclusive
+  if (t == 0) { inv_ptr[0] = 0; chunk_ptr[0] = 0; }
+  for (int n = n0; n < n1; ++n) {
+    const int deg = inv_ptr[n + 1];
+    rd += deg;
+    rc += (deg + GATHER_CHUNK - 1) / GATHER_CHUNK;
+    inv_ptr[n + 1] = rd;
+    chunk_ptr[n + 1] = rc;
+  }
+}
+
+// sel[m] = 1 where the edge's centre does not come after its target in the decoding order (the decoder read the
+// encoder block for it), in list order
+__global__ void __launch_bounds__(256)
+k_inv_sel(const int* __restrict__ rank, const int* __restrict__ inv_ptr, const int* __restrict__ inv_row, int N, int Kp,
+          unsigned char* __restrict__ sel) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int rn = rank[n], m1 = inv_ptr[n + 1];
+  for (int m = inv_ptr[n] + lane; m < m1; m += 64) sel[m] = rank[inv_row[m] / Kp] <= rn ? 1 : 0;
+}
+
 extern "C" int mpnn_gather_rows(const float* rows, const int32_t* inv_ptr, const int32_t* inv_row,
                                 const unsigned char* sel, const int32_t* chunk_ptr, int n_nodes, int max_chunks,
                                 float* outA, float* outB, void* stream) {
@@ -766,6 +853,36 @@ extern "C" int mpnn_gather_rows(const float* rows, const int32_t* inv_ptr, const
   MPNN_CHECK_ARG(n_nodes > 0 && max_chunks > 0 && (!sel || outB), "mpnn_gather_rows: a selector needs the second output");
   hipLaunchKernelGGL(k_gather_rows, dim3((max_chunks + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, inv_ptr, inv_row,
                      sel, chunk_ptr, n_nodes, max_chunks, outA, outB);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_inverse_lists(const int32_t* E_idx32, int B, int L, int K, unsigned char* slot_map, int32_t* inv_ptr,
+                                  int32_t* chunk_ptr, int32_t* inv_row, void* stream) {
+  MPNN_CHECK_ARG(E_idx32 && slot_map && inv_ptr && chunk_ptr && inv_row, "mpnn_inverse_lists: null pointer");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && K <= L, "mpnn_inverse_lists: bad sizes (1 <= K <= min(64, L))");
+  MPNN_CHECK_ARG((long long)B * L * K < (1ll << 31) && (long long)B * L < (1ll << 31) / 64,
+                 "mpnn_inverse_lists: more than 2^31 edges");
+  hipStream_t st = (hipStream_t)stream;
+  const int N = B * L, Kp = 16 * ((K + 15) / 16);
+  const long long n_edges = (long long)N * K;
+  if (hipMemsetAsync(slot_map, 0xFF, (size_t)N * L, st) != hipSuccess) {
+    mpnn_set_error("mpnn_inverse_lists: hipMemsetAsync failed");
+    return 1;
+  }
+  hipLaunchKernelGGL(k_inv_mark, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, st, E_idx32, n_edges, L, K, Kp,
+                     slot_map);
+  hipLaunchKernelGGL((k_inv_rows<false>), dim3((N + 3) / 4), dim3(256), 0, st, slot_map, N, L, Kp, inv_ptr, inv_row);
+  hipLaunchKernelGGL(k_inv_scan, dim3(1), dim3(1024), 0, st, N, inv_ptr, chunk_ptr);
+  hipLaunchKernelGGL((k_inv_rows<true>), dim3((N + 3) / 4), dim3(256), 0, st, slot_map, N, L, Kp, inv_ptr, inv_row);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_inverse_sel(const int32_t* rank, const int32_t* inv_ptr, const int32_t* inv_row, int n_nodes, int K,
+                                unsigned char* sel, void* stream) {
+  MPNN_CHECK_ARG(rank && inv_ptr && inv_row && sel, "mpnn_inverse_sel: null pointer");
+  MPNN_CHECK_ARG(n_nodes > 0 && K >= 1 && K <= 64, "mpnn_inverse_sel: bad sizes");
+  hipLaunchKernelGGL(k_inv_sel, dim3((n_nodes + 3) / 4), dim3(256), 0, (hipStream_t)stream, rank, inv_ptr, inv_row, n_nodes,
+                     16 * ((K + 15) / 16), sel);
   MPNN_LAUNCH_CHECK();
 }
 

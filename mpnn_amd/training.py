@@ -42,28 +42,58 @@ class Graph:
         self.KT = (K + 15) // 16
         self.Kp = 16 * self.KT
         self.E_idx64, self.E_idx32, self.mask, self.edge_mask = E_idx64, E_idx32, mask, edge_mask
-        base = (torch.arange(B, device=dev) * L).view(B, 1, 1)
-        self.dest = (E_idx64 + base).reshape(-1)                      # node each edge gathers from
-        src = torch.arange(self.N, device=dev).view(-1, 1)
-        rows = (src * self.Kp + torch.arange(K, device=dev).view(1, -1)).reshape(-1)
-        self.src = src.expand(-1, K).reshape(-1)
-        self.perm = torch.argsort(self.dest, stable=True)
-        self.inv_row = rows[self.perm].to(torch.int32).contiguous()
-        # (torch.bincount synchronises with the host to size its output; scatter_add does not)
-        counts = torch.zeros(self.N, device=dev, dtype=torch.int64).scatter_add_(0, self.dest, torch.ones_like(self.dest))
-        self.inv_ptr = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]).to(torch.int32).contiguous()
-        chunks = (counts + 31) // 32  # mpnn_gather_rows works on chunks of <= 32 list entries (hub residues!)
-        self.chunk_ptr = torch.cat([chunks.new_zeros(1), torch.cumsum(chunks, 0)]).to(torch.int32).contiguous()
         self.max_chunks = (self.N * K) // 32 + self.N
         self.rank = None
         self.sel = None
+        # inverse lists (edges grouped by the node they gather from, in the order of a stable sort by target)
+        n_edges = self.N * K
+        self.inv_ptr = torch.empty(self.N + 1, device=dev, dtype=torch.int32)
+        self.chunk_ptr = torch.empty(self.N + 1, device=dev, dtype=torch.int32)
+        self.inv_row = torch.empty(n_edges, device=dev, dtype=torch.int32)
+        if K <= L and self.N * L <= self.SLOT_MAP_LIMIT:
+            if E_idx32 is None:   # stand-alone use (tests): the padded int32 form mpnn_knn_topk would have written
+                E_idx32 = torch.zeros(self.N, self.Kp, device=dev, dtype=torch.int32)
+                E_idx32[:, :K] = E_idx64.reshape(self.N, K)
+            slot_map = torch.empty(self.N * L, device=dev, dtype=torch.uint8)
+            call("mpnn_inverse_lists", ptr(E_idx32), B, L, K, ptr(slot_map), ptr(self.inv_ptr), ptr(self.chunk_ptr),
+                 ptr(self.inv_row), stream_ptr())
+        else:
+            self._lists_by_sort(E_idx64)
+
+    @property
+    def dest(self):
+        """node each edge gathers from, [N K] in edge order"""
+        base = (torch.arange(self.B, device=self.E_idx64.device) * self.L).view(self.B, 1, 1)
+        return (self.E_idx64 + base).reshape(-1)
+
+    @property
+    def src(self):
+        """node each edge belongs to, [N K] in edge order"""
+        return torch.arange(self.N, device=self.E_idx64.device).view(-1, 1).expand(-1, self.K).reshape(-1)
+
+    SLOT_MAP_LIMIT = 1 << 30   # bytes of scratch mpnn_inverse_lists may take (B L^2); above: sort-based construction
+
+    def _lists_by_sort(self, E_idx64):
+        """The same lists from ATen ops (a stable sort of the edges by target): for batches whose B L^2-byte slot map
+        would be too large, and the check of mpnn_inverse_lists in tests/test_gpu_train.py."""
+        B, L, K, dev = self.B, self.L, self.K, E_idx64.device
+        dest = self.dest
+        src = torch.arange(self.N, device=dev).view(-1, 1)
+        rows = (src * self.Kp + torch.arange(K, device=dev).view(1, -1)).reshape(-1)
+        perm = torch.argsort(dest, stable=True)
+        self.inv_row = rows[perm].to(torch.int32).contiguous()
+        # (torch.bincount synchronises with the host to size its output; scatter_add does not)
+        counts = torch.zeros(self.N, device=dev, dtype=torch.int64).scatter_add_(0, dest, torch.ones_like(dest))
+        self.inv_ptr = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]).to(torch.int32).contiguous()
+        chunks = (counts + 31) // 32  # mpnn_gather_rows works on chunks of <= 32 list entries (hub residues!)
+        self.chunk_ptr = torch.cat([chunks.new_zeros(1), torch.cumsum(chunks, 0)]).to(torch.int32).contiguous()
 
     def set_order(self, rank):
         """rank [N] int32 decoding rank; sel = 1 where the edge read the encoder block (neighbour not yet decoded)."""
         self.rank = rank
-        r = rank.to(torch.int64)
-        sel = (r[self.src] <= r[self.dest]).to(torch.uint8)
-        self.sel = sel[self.perm].contiguous()
+        self.sel = torch.empty(self.N * self.K, device=rank.device, dtype=torch.uint8)
+        call("mpnn_inverse_sel", ptr(rank), ptr(self.inv_ptr), ptr(self.inv_row), self.N, self.K, ptr(self.sel),
+             stream_ptr())
 
     def frag_numel(self):
         return self.N * 8 * self.KT * 256

@@ -156,6 +156,34 @@ def test_wgrad_and_gather_kernels():
     assert float((outB.double() - wantB).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("B,L,K", [(2, 35, 30), (1, 100, 48), (3, 512, 64), (2, 70, 1), (1, 16, 16), (2, 131, 48)])
+def test_inverse_lists_match_stable_sort(B, L, K):
+    """mpnn_inverse_lists / mpnn_inverse_sel against the lists a stable sort of the edges by their target gives
+    (the ATen construction they replace): identical offsets, rows, chunk offsets and selectors."""
+    from mpnn_amd import training
+
+    g0 = torch.Generator().manual_seed(1000 * L + K)
+    d = "cuda"
+    # hub-heavy neighbour lists: residues near the start of a protein are picked far more often
+    w = 1.0 / (1.0 + torch.arange(L, dtype=torch.float64)) ** 0.7
+    E_idx = torch.stack([torch.stack([torch.multinomial(w, K, replacement=False, generator=g0) for _ in range(L)])
+                         for _ in range(B)]).to(d)
+    g = training.Graph(E_idx, None, None, None, K)
+    ref = training.Graph.__new__(training.Graph)
+    ref.__dict__.update(B=B, L=L, K=K, N=B * L, Kp=g.Kp, E_idx64=E_idx)
+    ref._lists_by_sort(E_idx)
+    torch.cuda.synchronize()
+    assert torch.equal(g.inv_ptr, ref.inv_ptr) and int(g.inv_ptr[-1]) == B * L * K
+    assert torch.equal(g.chunk_ptr, ref.chunk_ptr)
+    assert torch.equal(g.inv_row, ref.inv_row)
+    rank = torch.stack([torch.randperm(L, generator=g0) for _ in range(B)]).reshape(-1).to(d).to(torch.int32)
+    g.set_order(rank)
+    r = rank.long()
+    perm = torch.argsort(g.dest, stable=True)
+    want = (r[g.src] <= r[g.dest]).to(torch.uint8)[perm]
+    assert torch.equal(g.sel, want)
+
+
 @pytest.mark.parametrize("dropout,augment_eps", [(0.0, 0.0), (0.1, 0.1)])
 def test_train_steps_reduce_loss(dropout, augment_eps):
     """Eight AdamW steps on one synthetic batch through ProteinMPNN.forward in training mode (the reference's defaults
