@@ -392,6 +392,24 @@ __device__ __forceinline__ f32x4 quad_transpose(f32x4 v) {
   return v;
 }
 
+#ifndef MPNN_WGRAD_SPLIT_MIX
+#define MPNN_WGRAD_SPLIT_MIX 1  // hi / lo split as in split_pair (mpnn_common.h): 1.5 instead of 4 instructions per element
+#endif
+// x -> f16 hi (truncated) + f16 lo = f16(x - hi): v_cvt_pkrtz for two hi halves, one v_fma_mix per lo half.  The values
+// come from DPP moves / loads (never straight from an MFMA) and go to LDS stores.
+__device__ __forceinline__ void split4(const f32x4 x, h4& hi, h4& lo) {
+  unsigned h[2], l[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    h[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x[2 * j], x[2 * j + 1]));
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=&v"(l[j]) : "v"(h[j]), "v"(x[2 * j]));
+    asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l[j]) : "v"(h[j]), "v"(x[2 * j + 1]));
+  }
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  hi = __builtin_bit_cast(h4, (u32x2_t){h[0], h[1]});
+  lo = __builtin_bit_cast(h4, (u32x2_t){l[0], l[1]});
+}
+
 #ifndef MPNN_WGRAD_NT
 #define MPNN_WGRAD_NT 1  // operand streams by non-temporal loads
 #endif
@@ -495,6 +513,10 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
           a = quad_transpose(a);
           b = quad_transpose(b);
           h4 ah, al, bh, bl;
+#if MPNN_WGRAD_SPLIT_MIX
+          split4(a, ah, al);
+          split4(b, bh, bl);
+#else
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             ah[r] = (_Float16)a[r];
@@ -502,6 +524,7 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
             bh[r] = (_Float16)b[r];
             bl[r] = (_Float16)(b[r] - (float)bh[r]);
           }
+#endif
           const int frow = 16 * t + 4 * g + (col & 3), ecol = 16 * c + 4 * (col >> 2);
           *reinterpret_cast<h4*>(&sA[0][frow][ecol]) = ah;
           *reinterpret_cast<h4*>(&sA[1][frow][ecol]) = al;
