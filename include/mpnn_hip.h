@@ -442,6 +442,24 @@ int mpnn_dec_layer_subset(const float* hE_frag, const float* P, int ldp, int off
                           float scale, const float* Wproj_packed, const float* bproj, int nproj, float* hV_out,
                           float* PQ, void* stream);
 
+/* The LAST decoder layer of a level and the draw in one launch: mpnn_dec_layer_subset (without projections: no layer
+ * follows) and then mpnn_sample_subset on the same list - the workgroup that finished a residue's node features draws
+ * its letter and folds the sequence term into the layers' gathered rows.  Results identical to the two calls
+ * (model_utils.py:507-529; sampling has no counterpart in the reference, see mpnn_sample_subset).  K <= 48. */
+int mpnn_dec_layer_sample_subset(const float* hE_frag, const float* P, int ldp, int offP, const float* RowA, int lda,
+                                 int offA, const float* PVenc, int ldenc, int offEnc, const int32_t* rank,
+                                 const int32_t* E_idx32, const float* mask, const float* edge_mask,
+                                 const float* W1b_packed, const float* W2_packed, const float* b2,
+                                 const int32_t* node_list, int n_list, int enc_nodes, int L, int K, const float* hV_in,
+                                 float cnt_const, const float* W3_packed, const float* b3, const float* ln1_w,
+                                 const float* ln1_b, const float* Win_packed, const float* b_in,
+                                 const float* Wout_packed, const float* b_out, const float* ln2_w, const float* ln2_b,
+                                 float scale, float* hV_out, const float* Wlogit_packed, const float* blogit,
+                                 const float* logit_bias, int n_letters, float temperature, uint64_t seed,
+                                 const float* designable, const int64_t* S_in, int64_t* S_out, float* log_probs,
+                                 const float* TS, int ld_ts, int n_layers, float* const* A_rows, const int* A_ld,
+                                 const int* A_off, void* stream);
+
 /* mpnn_node_update (do_update = 1, cnt = cnt_const, no table add) for the residues in node_list; sets the gsum rows it
  * has read back to zero, ready for the next level's accumulation. */
 int mpnn_node_update_subset(const float* hV_in, float* gsum, float cnt_const, const float* mask,
@@ -524,6 +542,19 @@ int mpnn_dec_layer_subset_f16(const float* hE_frag, const float* P, int ldp, int
                               const float* Wout_packed, const float* b_out, const float* ln2_w, const float* ln2_b,
                               float scale, const float* Wproj_packed, const float* bproj, int nproj, float* hV_out,
                               float* PQ, void* stream);
+int mpnn_dec_layer_sample_subset_f16(const float* hE_frag, const float* P, int ldp, int offP, const float* RowA, int lda,
+                                 int offA, const float* PVenc, int ldenc, int offEnc, const int32_t* rank,
+                                 const int32_t* E_idx32, const float* mask, const float* edge_mask,
+                                 const float* W1b_packed, const float* W2_packed, const float* b2,
+                                 const int32_t* node_list, int n_list, int enc_nodes, int L, int K, const float* hV_in,
+                                 float cnt_const, const float* W3_packed, const float* b3, const float* ln1_w,
+                                 const float* ln1_b, const float* Win_packed, const float* b_in,
+                                 const float* Wout_packed, const float* b_out, const float* ln2_w, const float* ln2_b,
+                                 float scale, float* hV_out, const float* Wlogit_packed, const float* blogit,
+                                 const float* logit_bias, int n_letters, float temperature, uint64_t seed,
+                                 const float* designable, const int64_t* S_in, int64_t* S_out, float* log_probs,
+                                 const float* TS, int ld_ts, int n_layers, float* const* A_rows, const int* A_ld,
+                                 const int* A_off, void* stream);
 
 int mpnn_node_update_subset_f16(const float* hV_in, float* gsum, float cnt_const, const float* mask,
                             const float* W3_packed, const float* b3, const float* ln1_w, const float* ln1_b,

@@ -73,6 +73,8 @@ SIGNATURES = {
     "mpnn_dec_message_subset": [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I] + [_P] * 8 + [_I] * 4 + [_P, _P],
     "mpnn_dec_layer_subset": [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I] + [_P] * 8 + [_I] * 4 + [_P, _F] + [_P] * 10 +
                              [_F, _P, _P, _I, _P, _P, _P],
+    "mpnn_dec_layer_sample_subset": [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I] + [_P] * 8 + [_I] * 4 + [_P, _F] + [_P] * 10 +
+                                    [_F, _P] + [_P, _P, _P, _I, _F, ctypes.c_uint64] + [_P] * 5 + [_I, _I, _P, _P, _P, _P],
     "mpnn_node_update_subset": [_P, _P, _F, _P] + [_P] * 10 + [_F, _P, _P, _I, _P, _I, _P, _P, _P],
     "mpnn_sample_subset": [_P, _P, _P, _P, _I, _P, _I, _F, ctypes.c_uint64, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "mpnn_node_update_train": [_P, _P, _P, _F] + [_P] * 11 + [_F, _P, _P, _I, _I] + [_P] * 5 + [_F, ctypes.c_uint32, _P],
@@ -97,7 +99,7 @@ SIGNATURES = {
 
 # reduced-precision twins (one f16 product per fp32 product) of the forward entry points: same signatures
 F16_ENTRIES = ("mpnn_edge_features", "mpnn_enc_message", "mpnn_enc_edge_update", "mpnn_dec_message", "mpnn_node_update",
-               "mpnn_dec_message_subset", "mpnn_node_update_subset", "mpnn_dec_message_shared", "mpnn_dec_layer_subset",
+               "mpnn_dec_message_subset", "mpnn_node_update_subset", "mpnn_dec_message_shared", "mpnn_dec_layer_subset", "mpnn_dec_layer_sample_subset",
                "mpnn_linear_rows", "mpnn_edge_features_biased", "mpnn_dec_message_valid",
                "mpnn_decode_level", "mpnn_decode_plan")
 for _n in F16_ENTRIES:

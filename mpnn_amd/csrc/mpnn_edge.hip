@@ -1063,7 +1063,8 @@ level_node(h8* lds, float (*gsl)[MPNN_H], const W3Frags& w3, const int* __restri
            const float* __restrict__ ln1w, const float* __restrict__ ln1b, const h8* __restrict__ Win,
            const float* __restrict__ bin, const h8* __restrict__ Wout, const float* __restrict__ bout,
            const float* __restrict__ ln2w, const float* __restrict__ ln2b, float inv_scale,
-           const h8* __restrict__ Wproj, const float* __restrict__ bproj, int nproj, float* hV_out, float* PQ) {
+           const h8* __restrict__ Wproj, const float* __restrict__ bproj, int nproj, float* hV_out, float* PQ,
+           f32x4 (&h)[MPNN_NT][1]) {  // h: on return the columns' new node features (node waves)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, col = lane & 15;
   f32x4 (*ex)[MPNN_NT][64] = reinterpret_cast<f32x4 (*)[MPNN_NT][64]>(lds);
@@ -1071,7 +1072,7 @@ level_node(h8* lds, float (*gsl)[MPNN_H], const W3Frags& w3, const int* __restri
   const int idx = tile * lvn + col;
   const bool live = col < lvn && idx < n_list;
   const int nd = node_list[live ? idx : n_list - 1];
-  f32x4 h[MPNN_NT][1], o[MPNN_NT][1];
+  f32x4 o[MPNN_NT][1];
   BFrag xb[NKK][1];
   float mk = 1.0f;
   if (act) {
@@ -1141,6 +1142,12 @@ level_node(h8* lds, float (*gsl)[MPNN_H], const W3Frags& w3, const int* __restri
   }
 }
 
+#include "mpnn_sample.h"
+
+// HEAD: the launch of the LAST decoder layer also draws the residues' letters and folds their sequence terms into the
+// layers' gathered rows (what mpnn_sample_subset does in a launch of its own): wave 0 still holds the new node
+// features in the layout the head's GEMM wants.
+template <bool HEAD>
 __global__ void __launch_bounds__(MPNN_MSGT_WAVES * 64)
 k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp, int offP,
                   const float* __restrict__ Abuf, int lda, int offA, const float* __restrict__ Bbuf, int ldb, int offB,
@@ -1152,7 +1159,7 @@ k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, 
                   const h8* __restrict__ Win, const float* __restrict__ bin, const h8* __restrict__ Wout,
                   const float* __restrict__ bout, const float* __restrict__ ln2w, const float* __restrict__ ln2b,
                   float inv_scale, const h8* __restrict__ Wproj, const float* __restrict__ bproj, int nproj,
-                  float* __restrict__ hV_out, float* __restrict__ PQ, int lvn) {
+                  float* __restrict__ hV_out, float* __restrict__ PQ, int lvn, LevelHead head) {
   __shared__ h8 lds[2 * WSPLIT];
   __shared__ float gsl[16][MPNN_H];
   // the node phase's bias / LayerNorm vectors, copied to LDS while the message phase runs: read from global memory at
@@ -1205,9 +1212,27 @@ k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, 
 #endif
   __syncthreads();  // neighbour sums complete; the message weights in LDS are dead from here on
 #ifndef MPNN_ABL_LEVEL_NONODE
+  f32x4 hnew[MPNN_NT][1];
   level_node(lds, gsl, w3, node_list, n_list, tile, lvn, mask, hV_in, cnt_const, lprm, lprm + MPNN_H, lprm + 2 * MPNN_H, Win,
              lprm + 3 * MPNN_H, Wout, lprm + 7 * MPNN_H, lprm + 8 * MPNN_H, lprm + 9 * MPNN_H, inv_scale, Wproj,
-             lprm + LPRM_PROJ, nproj, hV_out, PQ);
+             lprm + LPRM_PROJ, nproj, hV_out, PQ, hnew);
+  if (HEAD) {
+    // gsl (the neighbour sums) was last read at the top of the node phase, three barriers ago
+    float (*pr)[33] = reinterpret_cast<float (*)[33]>(&gsl[0][0]);
+    int* pick = reinterpret_cast<int*>(&gsl[0][0] + 16 * 33);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+      const int col = lane & 15, idx = tile * lvn + col;
+      const bool live = col < lvn && idx < n_list;
+      const int nd = node_list[live ? idx : n_list - 1];
+      sample_columns_h(hnew, head.Wp, head.bias, head.logit_bias, head.n_letters, nd, live, head.inv_temperature,
+                       head.seed, head.designable, head.S_in, head.S_out, head.log_probs, pr, pick, lane);
+    }
+    __syncthreads();
+    fold_sequence_rows<MPNN_MSGT_WAVES, 2>(
+        [&](int l, int n) { return head.rows.A[l] + (size_t)n * head.rows.ld[l] + head.rows.off[l]; }, head.rows.n_layers,
+        head.TS, head.ld_ts, node_list + tile * lvn, nlive, pick, wave, lane);
+  }
 #else
   if (w3.hi[0][0] == (_Float16)77.f && gsl[1][1] == 5.f) hV_out[0] = 1.f;
 #endif
@@ -1321,8 +1346,9 @@ k_decode_level(const f32x4* __restrict__ hE, const float* __restrict__ PVenc, in
         for (int u = 0; u < 8; ++u) lds[WSPLIT + i0 + u * NT] = v[u];
       }
     }
+    f32x4 hnew_unused[MPNN_NT][1];
     level_node(lds, gsl, w3, node_list, n_list, tile, lvn, mask, (const float*)y.hV_in, cnt_const, (const float*)y.b3, (const float*)y.ln1w, (const float*)y.ln1b, (const h8*)y.Win, (const float*)y.bin,
-               (const h8*)y.Wout, (const float*)y.bout, (const float*)y.ln2w, (const float*)y.ln2b, y.inv_scale, (const h8*)y.Wproj, (const float*)y.bproj, y.nproj, (float*)y.hV_out, (float*)y.PQ);
+               (const h8*)y.Wout, (const float*)y.bout, (const float*)y.ln2w, (const float*)y.ln2b, y.inv_scale, (const h8*)y.Wproj, (const float*)y.bproj, y.nproj, (float*)y.hV_out, (float*)y.PQ, hnew_unused);
     STAMP(4);
     // the tile's hV / P rows written above are read by the next layer (or the head) of this workgroup, and the next
     // layer's LDS fill overwrites the exchange buffer
@@ -1633,11 +1659,63 @@ extern "C" int MPNN_API(mpnn_dec_layer_subset)(const float* hE_frag, const float
                  "mpnn_dec_layer_subset: bad sizes (K <= 48; at most 8 projection blocks; strides/offsets multiples of 4 floats)");
   const int KT = (K + 15) / 16;
   const int lvn = level_nodes_per_wg(n_list);
-  hipLaunchKernelGGL(k_dec_layer_level, dim3(ceil_div(n_list, lvn)), dim3(MPNN_MSGT_WAVES * 64), 0, (hipStream_t)stream,
-                     (const f32x4*)hE_frag, P, ldp, offP, RowA, lda, offA, PVenc, ldenc, offEnc, rank, E_idx32, mask,
-                     edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2, node_list, n_list, enc_nodes, L, K, KT,
-                     hV_in, cnt_const, (const h8*)W3_packed, b3, ln1_w, ln1_b, (const h8*)Win_packed, b_in,
-                     (const h8*)Wout_packed, b_out, ln2_w, ln2_b, 1.0f / scale, (const h8*)Wproj_packed, bproj, nproj,
-                     hV_out, PQ, lvn);
+  hipLaunchKernelGGL((k_dec_layer_level<false>), dim3(ceil_div(n_list, lvn)), dim3(MPNN_MSGT_WAVES * 64), 0,
+                     (hipStream_t)stream, (const f32x4*)hE_frag, P, ldp, offP, RowA, lda, offA, PVenc, ldenc, offEnc, rank,
+                     E_idx32, mask, edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2, node_list, n_list,
+                     enc_nodes, L, K, KT, hV_in, cnt_const, (const h8*)W3_packed, b3, ln1_w, ln1_b, (const h8*)Win_packed,
+                     b_in, (const h8*)Wout_packed, b_out, ln2_w, ln2_b, 1.0f / scale, (const h8*)Wproj_packed, bproj,
+                     nproj, hV_out, PQ, lvn, LevelHead{});
+  MPNN_LAUNCH_CHECK();
+}
+
+// mpnn_dec_layer_subset of the LAST decoder layer (no projections follow) + mpnn_sample_subset on the same list, in
+// one launch
+extern "C" int MPNN_API(mpnn_dec_layer_sample_subset)(
+    const float* hE_frag, const float* P, int ldp, int offP, const float* RowA, int lda, int offA, const float* PVenc,
+    int ldenc, int offEnc, const int32_t* rank, const int32_t* E_idx32, const float* mask, const float* edge_mask,
+    const float* W1b_packed, const float* W2_packed, const float* b2, const int32_t* node_list, int n_list, int enc_nodes,
+    int L, int K, const float* hV_in, float cnt_const, const float* W3_packed, const float* b3, const float* ln1_w,
+    const float* ln1_b, const float* Win_packed, const float* b_in, const float* Wout_packed, const float* b_out,
+    const float* ln2_w, const float* ln2_b, float scale, float* hV_out, const float* Wlogit_packed, const float* blogit,
+    const float* logit_bias, int n_letters, float temperature, uint64_t seed, const float* designable,
+    const int64_t* S_in, int64_t* S_out, float* log_probs, const float* TS, int ld_ts, int n_layers,
+    float* const* A_rows, const int* A_ld, const int* A_off, void* stream) {
+  MPNN_CHECK_ARG(hE_frag && P && RowA && PVenc && rank && E_idx32 && mask && W1b_packed && W2_packed && b2 &&
+                     node_list && hV_in && W3_packed && b3 && ln1_w && ln1_b && Win_packed && b_in && Wout_packed &&
+                     b_out && ln2_w && ln2_b && hV_out && Wlogit_packed && blogit && designable && S_in && S_out &&
+                     log_probs && TS && A_rows && A_ld && A_off,
+                 "mpnn_dec_layer_sample_subset: null pointer");
+  MPNN_CHECK_ARG(n_list > 0 && L > 0 && enc_nodes > 0 && enc_nodes % L == 0 && K >= 1 && K <= 48 && scale != 0.f &&
+                     mult4(ldp, offP, lda, offA, ldenc, offEnc) && n_letters >= 1 && n_letters <= 32 &&
+                     temperature > 0.f && n_layers >= 0 && n_layers <= 4,
+                 "mpnn_dec_layer_sample_subset: bad sizes (K <= 48; n_letters <= 32; temperature > 0; at most 4 decoder "
+                 "layers; strides/offsets multiples of 4 floats)");
+  LevelHead head;
+  head.Wp = (const f32x4*)Wlogit_packed;
+  head.bias = blogit;
+  head.logit_bias = logit_bias;
+  head.n_letters = n_letters;
+  head.inv_temperature = 1.0f / temperature;
+  head.seed = (unsigned long long)seed;
+  head.designable = designable;
+  head.S_in = (const long long*)S_in;
+  head.S_out = (long long*)S_out;
+  head.log_probs = log_probs;
+  head.TS = TS;
+  head.ld_ts = ld_ts;
+  head.rows.n_layers = n_layers;
+  for (int l = 0; l < 4; ++l) {
+    head.rows.A[l] = l < n_layers ? A_rows[l] : nullptr;
+    head.rows.ld[l] = l < n_layers ? A_ld[l] : 0;
+    head.rows.off[l] = l < n_layers ? A_off[l] : 0;
+  }
+  const int KT = (K + 15) / 16;
+  const int lvn = level_nodes_per_wg(n_list);
+  hipLaunchKernelGGL((k_dec_layer_level<true>), dim3(ceil_div(n_list, lvn)), dim3(MPNN_MSGT_WAVES * 64), 0,
+                     (hipStream_t)stream, (const f32x4*)hE_frag, P, ldp, offP, RowA, lda, offA, PVenc, ldenc, offEnc, rank,
+                     E_idx32, mask, edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2, node_list, n_list,
+                     enc_nodes, L, K, KT, hV_in, cnt_const, (const h8*)W3_packed, b3, ln1_w, ln1_b, (const h8*)Win_packed,
+                     b_in, (const h8*)Wout_packed, b_out, ln2_w, ln2_b, 1.0f / scale, (const h8*)nullptr,
+                     (const float*)nullptr, 0, hV_out, (float*)nullptr, lvn, head);
   MPNN_LAUNCH_CHECK();
 }

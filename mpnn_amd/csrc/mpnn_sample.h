@@ -13,6 +13,23 @@ struct SampleRows {
   int n_layers;
 };
 
+// everything the head needs beyond the residues' features (k_dec_layer_level<true>: the last decoder layer's launch
+// also draws)
+struct LevelHead {
+  const f32x4* Wp;
+  const float *bias, *logit_bias;
+  int n_letters;
+  float inv_temperature;
+  unsigned long long seed;
+  const float* designable;
+  const long long* S_in;
+  long long* S_out;
+  float* log_probs;
+  const float* TS;
+  int ld_ts;
+  SampleRows rows;
+};
+
 __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long ctr) {
   unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1);  // splitmix64
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -23,16 +40,15 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned lon
 
 // One wave: logits, log-probs and the draw for the residue `nd` of this lane's column (col = lane & 15; `live`
 // columns write).  pr: 16 x 33 floats of LDS scratch, pick: 16 ints; pick[col] <- the letter.
-__device__ __forceinline__ void sample_columns(const float* __restrict__ hV, const f32x4* __restrict__ Wp,
-                                               const float* __restrict__ bias, const float* __restrict__ logit_bias,
-                                               int n_letters, int nd, bool live, float inv_temperature,
-                                               unsigned long long seed, const float* __restrict__ designable,
-                                               const long long* __restrict__ S_in, long long* __restrict__ S_out,
-                                               float* __restrict__ log_probs, float (*pr)[33], int* pick, int lane) {
+// h: the residues' final node features as the lane holds them (features 16 t + 4 g .. + 3 of column col)
+__device__ __forceinline__ void sample_columns_h(const f32x4 (&h)[MPNN_NT][1], const f32x4* __restrict__ Wp,
+                                                 const float* __restrict__ bias, const float* __restrict__ logit_bias,
+                                                 int n_letters, int nd, bool live, float inv_temperature,
+                                                 unsigned long long seed, const float* __restrict__ designable,
+                                                 const long long* __restrict__ S_in, long long* __restrict__ S_out,
+                                                 float* __restrict__ log_probs, float (*pr)[33], int* pick, int lane) {
   const int g = lane >> 4, col = lane & 15;
-  f32x4 h[MPNN_NT][1], y[2][1];
-#pragma unroll
-  for (int t = 0; t < MPNN_NT; ++t) h[t][0] = *reinterpret_cast<const f32x4*>(hV + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+  f32x4 y[2][1];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -106,6 +122,20 @@ __device__ __forceinline__ void sample_columns(const float* __restrict__ hV, con
     pick[col] = s;
     if (live) S_out[nd] = s;
   }
+}
+
+__device__ __forceinline__ void sample_columns(const float* __restrict__ hV, const f32x4* __restrict__ Wp,
+                                               const float* __restrict__ bias, const float* __restrict__ logit_bias,
+                                               int n_letters, int nd, bool live, float inv_temperature,
+                                               unsigned long long seed, const float* __restrict__ designable,
+                                               const long long* __restrict__ S_in, long long* __restrict__ S_out,
+                                               float* __restrict__ log_probs, float (*pr)[33], int* pick, int lane) {
+  const int g = lane >> 4;
+  f32x4 h[MPNN_NT][1];
+#pragma unroll
+  for (int t = 0; t < MPNN_NT; ++t) h[t][0] = *reinterpret_cast<const f32x4*>(hV + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+  sample_columns_h(h, Wp, bias, logit_bias, n_letters, nd, live, inv_temperature, seed, designable, S_in, S_out, log_probs,
+                   pr, pick, lane);
 }
 
 // Fold the sequence term of the chosen letters into every decoder layer's A rows (2 floats per lane per row); the

@@ -780,20 +780,28 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
         head = [ptr(hVs[n_dec]), ptr(pw.Wlogit), ptr(pw.blogit), ptr(lb), pw.n_letters, None, 0, float(temperature),
                 int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(designable), ptr(S_in), ptr(S_out), ptr(log_probs), ptr(pw.TS),
                 pw.TS.shape[1], n_dec, A_rows, A_ld, A_off, st]
-        # MPNN_SAMPLE_LAUNCHES: "layer" (default) = one launch per decoder layer and level plus the head; "layer+draw" =
-        # the last layer's launch also draws (mpnn_decode_level from the last layer); "level" = one launch per level
-        # (mpnn_decode_level).  Both fused forms measured SLOWER on MI355X (one L = 512 sample: 6.7 ms / 7.3 ms /
-        # 8.1 ms).  "split" = message / node update / head launches
+        # MPNN_SAMPLE_LAUNCHES: "layer" (default) = one launch per decoder layer and level, the last one also drawing
+        # (mpnn_dec_layer_sample_subset); "layer/head" = the draw in a launch of its own (mpnn_sample_subset);
+        # "layer+draw" = the last layer and the draw through mpnn_decode_level; "level" = one launch per level
+        # (mpnn_decode_level).  The two mpnn_decode_level forms measured SLOWER on MI355X (one L = 512 sample: 6.7 ms
+        # for "layer/head", 7.3 ms / 8.1 ms).  "split" = message / node update / head launches
+        # "layer/head": as "layer" with the draw in a launch of its own (the last layer's launch draws by default)
         mode = os.environ.get("MPNN_SAMPLE_LAUNCHES", "layer")
+        head_fused = mode == "layer" and plans[-1][2][37] == 0   # the last decoder layer has no projections
+        if mode == "layer/head":
+            mode = "layer"
         if os.environ.get("MPNN_SAMPLE_UNFUSED") == "1" or K > 48:
             mode = "split"  # the fused level kernels give a workgroup four residues x three column tiles (K <= 48)
         f_layer = getattr(lib, _lib.entry("mpnn_dec_layer_subset"))
+        f_last = getattr(lib, _lib.entry("mpnn_dec_layer_sample_subset"))
+        last = plans[-1][2][:35] + [plans[-1][2][38]] + head[1:5] + head[7:19] + [st]
         f_msg = getattr(lib, _lib.entry("mpnn_dec_message_subset"))
         f_node = getattr(lib, _lib.entry("mpnn_node_update_subset"))
         f_head = lib.mpnn_sample_subset
         f_level = getattr(lib, _lib.entry("mpnn_decode_level"))
         if _lib._profile is not None:  # bench.py's per-entry-point timing goes through the generic wrapper
             f_layer = lambda *a: (call("mpnn_dec_layer_subset", *a), 0)[1]
+            f_last = lambda *a: (call("mpnn_dec_layer_sample_subset", *a), 0)[1]
             f_msg = lambda *a: (call("mpnn_dec_message_subset", *a), 0)[1]
             f_node = lambda *a: (call("mpnn_node_update_subset", *a), 0)[1]
             f_head = lambda *a: (call("mpnn_sample_subset", *a), 0)[1]
@@ -835,6 +843,13 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
                     rc = rc or f_layer(*layer)
                 level[7], level[8] = p_nodes, cnt_l
                 rc = rc or f_level(*level)
+                continue
+            if mode == "layer" and head_fused and K <= 48:
+                for msg, node, layer in plans[:-1]:
+                    layer[17], layer[18] = p_nodes, cnt_l
+                    rc = rc or f_layer(*layer)
+                last[17], last[18] = p_nodes, cnt_l
+                rc = rc or f_last(*last)
                 continue
             for msg, node, layer in plans:
                 if mode == "layer":
