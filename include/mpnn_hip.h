@@ -479,6 +479,29 @@ int mpnn_sample_subset(const float* hV, const float* Wout_packed, const float* b
                        const float* TS, int ld_ts, int n_layers, float* const* A_rows, const int* A_ld,
                        const int* A_off, void* stream);
 
+/* The whole decoder of a sampling call in ONE call: walks the levels (node_list = the residue ids sorted by level,
+ * DEVICE; level_counts [n_levels] = residues per level, HOST) and enqueues, per level, mpnn_dec_layer_subset for every
+ * decoder layer but the last and mpnn_dec_layer_sample_subset for the last (draw_fused = 1), or mpnn_dec_layer_subset
+ * for all layers followed by mpnn_sample_subset (draw_fused = 0) - the same launches, in the same order, with the same
+ * results as those per-level calls, issued from C instead of ~4 ctypes calls per level (the host side of a Python
+ * loop over ~70 levels x 3 launches was 3 of the 7.7 ms of a 64 x 512 sampling call).  `layers` is a HOST array of
+ * n_layers mpnn_level_layer (as for mpnn_decode_plan; layers[n_layers-1].nproj must be 0); the A rows the draw folds
+ * the sequence term into are layers[l].RowA / lda / offA.  Returns at the first failing launch.  K <= 48.
+ * No reference counterpart (the reference has no sampler). */
+int mpnn_decode_run(const float* hE_frag, const float* PVenc, int ldenc, const int32_t* rank, const int32_t* E_idx32,
+                    const float* mask, const float* edge_mask, const int32_t* node_list, const int32_t* level_counts,
+                    int n_levels, int enc_nodes, int L, int K, float cnt_const, const mpnn_level_layer* layers,
+                    int n_layers, const float* Wlogit_packed, const float* logit_b, const float* logit_bias,
+                    int n_letters, float temperature, uint64_t seed, const float* designable, const int64_t* S_in,
+                    int64_t* S_out, float* log_probs, const float* TS, int ld_ts, int draw_fused, void* stream);
+int mpnn_decode_run_f16(const float* hE_frag, const float* PVenc, int ldenc, const int32_t* rank,
+                        const int32_t* E_idx32, const float* mask, const float* edge_mask, const int32_t* node_list,
+                        const int32_t* level_counts, int n_levels, int enc_nodes, int L, int K, float cnt_const,
+                        const mpnn_level_layer* layers, int n_layers, const float* Wlogit_packed, const float* logit_b,
+                        const float* logit_bias, int n_letters, float temperature, uint64_t seed,
+                        const float* designable, const int64_t* S_in, int64_t* S_out, float* log_probs, const float* TS,
+                        int ld_ts, int draw_fused, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Reduced-precision forward ("f16 products"; BASELINE configs[3] asks for bf16-class message MLPs): the same
  * kernels compiled with ONE f16 MFMA product per fp32 product (operands rounded to f16, 11 significant bits - three

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 
 import torch  # noqa: F401  (must be imported first: the library binds to the HIP runtime torch loaded)
 
@@ -52,6 +53,8 @@ SIGNATURES = {
     "mpnn_decode_plan": [ctypes.POINTER(LevelLayer), _I, _P, _P],
     "mpnn_decode_level": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P, _P,
                           _I, _F, _U64, _P, _P, _P, _P, _P, _I, _P],
+    "mpnn_decode_run": [_P, _P, _I, _P, _P, _P, _P, _P, ctypes.POINTER(_I), _I, _I, _I, _I, _F,
+                        ctypes.POINTER(LevelLayer), _I, _P, _P, _P, _I, _F, _U64, _P, _P, _P, _P, _P, _I, _I, _P],
     "mpnn_node_update": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _I,
                          _P, _I, _I, _P, _I, _I, _P, _P, _P],
     "mpnn_occupancy_mlp": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
@@ -101,25 +104,35 @@ SIGNATURES = {
 F16_ENTRIES = ("mpnn_edge_features", "mpnn_enc_message", "mpnn_enc_edge_update", "mpnn_dec_message", "mpnn_node_update",
                "mpnn_dec_message_subset", "mpnn_node_update_subset", "mpnn_dec_message_shared", "mpnn_dec_layer_subset", "mpnn_dec_layer_sample_subset",
                "mpnn_linear_rows", "mpnn_edge_features_biased", "mpnn_dec_message_valid",
-               "mpnn_decode_level", "mpnn_decode_plan")
+               "mpnn_decode_level", "mpnn_decode_plan", "mpnn_decode_run")
 for _n in F16_ENTRIES:
     SIGNATURES[_n + "_f16"] = SIGNATURES[_n]
 
 _lib = None
-_suffix = ""
+
+
+class _Mode(threading.local):
+    """Precision mode of the CALLING THREAD: ctypes releases the GIL around library calls, so two models with different
+    precisions on two threads interleave; a module-global mode would let one retarget the other's entry points."""
+    suffix = ""
+
+
+_mode = _Mode()
 
 
 def set_precision(mode: str):
-    """'fp32' (default: 3 f16 products per fp32 product, fp32-class) or 'f16' (1 product) for the forward kernels."""
-    global _suffix
+    """'fp32' (default: 3 f16 products per fp32 product, fp32-class) or 'f16' (1 product) for the forward kernels the
+    calling thread launches from here on.  -> the previous mode (restore it with another call)."""
     if mode not in ("fp32", "f16"):
         raise ValueError("precision must be 'fp32' or 'f16'")
-    _suffix = "_f16" if mode == "f16" else ""
+    prev = "f16" if _mode.suffix else "fp32"
+    _mode.suffix = "_f16" if mode == "f16" else ""
+    return prev
 
 
 def entry(name: str) -> str:
-    """Entry-point name under the current precision mode."""
-    return name + _suffix if _suffix and name in F16_ENTRIES else name
+    """Entry-point name under the calling thread's precision mode."""
+    return name + _mode.suffix if _mode.suffix and name in F16_ENTRIES else name
 
 
 def load() -> ctypes.CDLL:

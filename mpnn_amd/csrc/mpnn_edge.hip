@@ -1719,3 +1719,72 @@ extern "C" int MPNN_API(mpnn_dec_layer_sample_subset)(
                      (const float*)nullptr, 0, hV_out, (float*)nullptr, lvn, head);
   MPNN_LAUNCH_CHECK();
 }
+
+// ---- the sampler's whole level loop in one call ----
+// The decoder of a sampling call is ~70 dependency levels x (decoder layers) dependent launches; issued one ctypes call
+// at a time from Python they cost ~11 us of host time each, more than the kernels behind them take.  This entry point
+// walks the host array of level sizes and enqueues the same launches (mpnn_dec_layer_subset for every layer but the
+// last, then mpnn_dec_layer_sample_subset - or mpnn_dec_layer_subset + mpnn_sample_subset with draw_fused = 0) on the
+// passed stream: same kernels, same order, same results as the per-level calls; no allocation, no synchronisation.
+// (the sampling head has one build: its arithmetic is fp32 in both precision modes)
+extern "C" int mpnn_sample_subset(const float* hV, const float* Wout_packed, const float* bias, const float* logit_bias,
+                                  int n_letters, const int32_t* node_list, int n_list, float temperature,
+                                  uint64_t seed, const float* designable, const int64_t* S_in, int64_t* S_out,
+                                  float* log_probs, const float* TS, int ld_ts, int n_layers, float* const* A_rows,
+                                  const int* A_ld, const int* A_off, void* stream);
+
+extern "C" int MPNN_API(mpnn_decode_run)(const float* hE_frag, const float* PVenc, int ldenc, const int32_t* rank,
+                                         const int32_t* E_idx32, const float* mask, const float* edge_mask,
+                                         const int32_t* node_list, const int32_t* level_counts, int n_levels,
+                                         int enc_nodes, int L, int K, float cnt_const, const mpnn_level_layer* layers,
+                                         int n_layers, const float* Wlogit_packed, const float* logit_b,
+                                         const float* logit_bias, int n_letters, float temperature, uint64_t seed,
+                                         const float* designable, const int64_t* S_in, int64_t* S_out, float* log_probs,
+                                         const float* TS, int ld_ts, int draw_fused, void* stream) {
+  MPNN_CHECK_ARG(node_list && level_counts && layers && n_levels >= 0 && n_layers >= 1 && n_layers <= 4,
+                 "mpnn_decode_run: need the level list, its host array of sizes and 1..4 layers");
+  MPNN_CHECK_ARG(layers[n_layers - 1].nproj == 0, "mpnn_decode_run: the last decoder layer carries no projections");
+  float* A_rows[4] = {};
+  int A_ld[4] = {}, A_off[4] = {};
+  for (int l = 0; l < n_layers; ++l) {
+    // a layer's input rows must be the previous layer's outputs (as mpnn_decode_plan demands)
+    MPNN_CHECK_ARG(l == 0 || (layers[l].hV_in == layers[l - 1].hV_out && layers[l - 1].nproj >= 2),
+                   "mpnn_decode_run: layer l must read the hV rows (and Pa | A projections) layer l-1 writes");
+    A_rows[l] = layers[l].RowA;
+    A_ld[l] = layers[l].lda;
+    A_off[l] = layers[l].offA;
+  }
+  long long start = 0;
+  for (int v = 0; v < n_levels; ++v) {
+    const int n_list = level_counts[v];
+    MPNN_CHECK_ARG(n_list > 0, "mpnn_decode_run: empty level");
+    const int32_t* list = node_list + start;
+    start += n_list;
+    for (int l = 0; l < n_layers; ++l) {
+      const mpnn_level_layer& y = layers[l];
+      int rc;
+      if (l + 1 < n_layers || !draw_fused) {
+        rc = MPNN_API(mpnn_dec_layer_subset)(hE_frag, y.P, y.ldp, y.offP, y.RowA, y.lda, y.offA, PVenc, ldenc, y.offEnc,
+                                             rank, E_idx32, mask, edge_mask, y.W1b_packed, y.W2_packed, y.b2, list,
+                                             n_list, enc_nodes, L, K, y.hV_in, cnt_const, y.W3_packed, y.b3, y.ln1_w,
+                                             y.ln1_b, y.Win_packed, y.b_in, y.Wout8_packed, y.b_out, y.ln2_w, y.ln2_b,
+                                             y.scale, y.Wproj_packed, y.bproj, y.nproj, y.hV_out, y.PQ, stream);
+      } else {
+        rc = MPNN_API(mpnn_dec_layer_sample_subset)(
+            hE_frag, y.P, y.ldp, y.offP, y.RowA, y.lda, y.offA, PVenc, ldenc, y.offEnc, rank, E_idx32, mask, edge_mask,
+            y.W1b_packed, y.W2_packed, y.b2, list, n_list, enc_nodes, L, K, y.hV_in, cnt_const, y.W3_packed, y.b3,
+            y.ln1_w, y.ln1_b, y.Win_packed, y.b_in, y.Wout8_packed, y.b_out, y.ln2_w, y.ln2_b, y.scale, y.hV_out,
+            Wlogit_packed, logit_b, logit_bias, n_letters, temperature, seed, designable, S_in, S_out, log_probs, TS,
+            ld_ts, n_layers, A_rows, A_ld, A_off, stream);
+      }
+      if (rc) return rc;
+    }
+    if (!draw_fused) {
+      const int rc = mpnn_sample_subset(layers[n_layers - 1].hV_out, Wlogit_packed, logit_b, logit_bias, n_letters, list,
+                                        n_list, temperature, seed, designable, S_in, S_out, log_probs, TS, ld_ts,
+                                        n_layers, A_rows, A_ld, A_off, stream);
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}

@@ -186,7 +186,9 @@ k_grad_sumsq(MultiTensor t, float* __restrict__ sumsq) {
 __device__ __forceinline__ float clip_coef(const float* sumsq, float max_norm) {
   if (!sumsq || !(max_norm > 0.f)) return 1.0f;
   const float c = max_norm / (sqrtf(*sumsq) + 1e-6f);
-  return c < 1.0f ? c : 1.0f;
+  // a NaN norm propagates, as torch's clamp(nan, max = 1) does: every gradient becomes NaN, an obvious failure (an
+  // infinite norm gives 0 there and here: finite gradients are zeroed, the infinite ones become NaN)
+  return c < 1.0f || c != c ? c : 1.0f;
 }
 
 __global__ void __launch_bounds__(256)
@@ -195,7 +197,7 @@ k_grad_scale(MultiTensor t, const float* __restrict__ sumsq, float max_norm) {
   const int i0 = blockIdx.x * MT_CHUNK;
   if (i0 >= n) return;
   const float c = clip_coef(sumsq, max_norm);
-  if (c == 1.0f) return;
+  if (c == 1.0f) return;  // (false for NaN: the scaling below then runs)
   float* g = t.p[ti];  // the gradient travels in the p slot for this kernel
   for (int i = i0 + threadIdx.x; i < min(n, i0 + MT_CHUNK); i += 256) g[i] *= c;
 }

@@ -15,6 +15,7 @@ from __future__ import annotations
 from typing import Optional
 
 import os
+import warnings
 
 import torch
 
@@ -187,59 +188,83 @@ def check_weight_range(model):
                            f"|w| < {F16_MAX:.0f} (operands are split into f16 hi + lo halves for the matrix pipe)")
 
 
+class NumericsWarning(RuntimeWarning):
+    """An EARLIER call of this model produced inf / NaN log-probs (found without blocking at the start of a later call)."""
+
+
 class NumericsGuard:
-    """Device-side overflow flag of one model.  After every forward / sampling call `mpnn_range_flag` ORs a bit into
-    the flag when a log-prob is inf / NaN - what an activation beyond the f16-split range (|x| >= 131008) turns into.
-    The flag travels to pinned host memory asynchronously; it is looked at without blocking at the start of the
-    model's next call (an overflow is then reported one call late) and with blocking by `check()`.  Nothing here
-    synchronises the stream on the hot path, and nothing is done while a HIP graph is being captured."""
+    """Device-side overflow flags of one model.  After every forward / sampling call `mpnn_range_flag` sets the call's
+    own flag slot when a log-prob is inf / NaN - what an activation beyond the f16-split range (|x| >= 131008) turns
+    into.  The slot travels to pinned host memory asynchronously.  Calls are numbered (`serial`, from 1), so a report
+    names the call it belongs to:
+      * `poll()` (start of the model's next call, non-blocking) only WARNS (NumericsWarning) about finished bad calls
+        and lets the current call run: one bad request must not abort the valid one that follows it;
+      * `check()` (`model.check_numerics()`, blocking) raises RuntimeError naming every bad call since the last check.
+    Nothing here synchronises the stream on the hot path, and nothing is done while a HIP graph is being captured."""
 
     SLOTS = 32
+    WHY = ("an activation or weight left the range of the f16-split matrix-pipe arithmetic (|x| < 65504, "
+           "include/mpnn_hip.h OPERAND RANGE), or the inputs were not finite")
 
     def __init__(self, dev):
-        self.flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.flags = torch.zeros(self.SLOTS, device=dev, dtype=torch.int32)
         self.host = torch.zeros(self.SLOTS, dtype=torch.int32).pin_memory()
-        self.pending = []  # (event, slot, description)
-        self.next = 0
+        self.pending = []  # (event, slot, serial, description)
+        self.serial = 0    # calls watched so far
+        self.failed = []   # (serial, description) of bad calls not yet raised by check()
 
     def watch(self, t, what):
+        """-> the call's serial number (0 when nothing was recorded)."""
         if torch.cuda.is_current_stream_capturing() or os.environ.get("MPNN_NO_NUMERICS_GUARD") == "1":
-            return  # (the switch is for timing-only ablation builds of the library, whose outputs are garbage)
-        call("mpnn_range_flag", ptr(t), t.numel(), float("inf"), ptr(self.flag), 1, stream_ptr())
+            return 0  # (the switch is for timing-only ablation builds of the library, whose outputs are garbage)
         if len(self.pending) >= self.SLOTS:
-            self.poll(block=True)
-        slot = self.next
-        self.next = (self.next + 1) % self.SLOTS
-        self.host[slot:slot + 1].copy_(self.flag, non_blocking=True)
+            self.failed += self._collect(block=True)
+        self.serial += 1
+        slot = self.serial % self.SLOTS
+        call("mpnn_range_flag", ptr(t), t.numel(), float("inf"), self.flags.data_ptr() + 4 * slot, 1, stream_ptr())
+        self.host[slot:slot + 1].copy_(self.flags[slot:slot + 1], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self.pending.append((ev, slot, what))
+        self.pending.append((ev, slot, self.serial, what))
+        return self.serial
 
-    def poll(self, block=False):
-        if not self.pending or torch.cuda.is_current_stream_capturing():
-            return
-        bad = None
-        keep = []
-        for ev, slot, what in self.pending:
+    def _collect(self, block):
+        """Finished calls leave `pending`; -> [(serial, description)] of those that were bad."""
+        bad, keep = [], []
+        for ev, slot, serial, what in self.pending:
             if block:
                 ev.synchronize()
             if ev.query():
-                if int(self.host[slot]) != 0 and bad is None:
-                    bad = what
+                if int(self.host[slot]) != 0:
+                    bad.append((serial, what))
+                    self.flags[slot:slot + 1].zero_()  # the slot is reused SLOTS calls later
+                    self.host[slot] = 0
             else:
-                keep.append((ev, slot, what))
+                keep.append((ev, slot, serial, what))
         self.pending = keep
-        if bad is not None:
-            self.flag.zero_()
-            self.pending = []
-            raise RuntimeError(f"mpnn_amd: {bad} produced inf / NaN log-probs: an activation or weight left the range of "
-                               "the f16-split matrix-pipe arithmetic (|x| < 65504, include/mpnn_hip.h OPERAND RANGE), or "
-                               "the inputs were not finite")
+        return bad
+
+    def poll(self):
+        if not self.pending or torch.cuda.is_current_stream_capturing():
+            return
+        for serial, what in self._collect(block=False):
+            self.failed.append((serial, what))
+            warnings.warn(NumericsWarning(f"mpnn_amd: call #{serial} of this model ({what}) produced inf / NaN log-probs: "
+                                          f"{self.WHY}; the current call (#{self.serial + 1}) runs as usual"), stacklevel=4)
+
+    def check(self):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        self.failed += self._collect(block=True)
+        if self.failed:
+            failed, self.failed = self.failed[-self.SLOTS:], []
+            calls = ", ".join(f"#{n} ({w})" for n, w in failed)
+            raise RuntimeError(f"mpnn_amd: call {calls} of {self.serial} produced inf / NaN log-probs: {self.WHY}")
 
 
 def numerics_guard(model, dev) -> NumericsGuard:
     g = model.__dict__.get("_numerics")
-    if g is None or g.flag.device != dev:
+    if g is None or g.flags.device != dev:
         g = NumericsGuard(dev)
         model.__dict__["_numerics"] = g
     return g
@@ -258,12 +283,11 @@ def packed(model) -> PackedWeights:
     pw = getattr(model, "_packed", None)
     if pw is None or pw.key != PackedWeights.make_key(model):
         check_weight_range(model)
-        saved = _lib._suffix  # derived tables (TS) are always built with fp32-class products
-        _lib._suffix = ""
+        saved = _lib.set_precision("fp32")  # derived tables (TS) are always built with fp32-class products
         try:
             pw = PackedWeights(model)
         finally:
-            _lib._suffix = saved
+            _lib.set_precision(saved)
         model._packed = pw
     return pw
 
@@ -786,7 +810,12 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
         # (mpnn_decode_level).  The two mpnn_decode_level forms measured SLOWER on MI355X (one L = 512 sample: 6.7 ms
         # for "layer/head", 7.3 ms / 8.1 ms).  "split" = message / node update / head launches
         # "layer/head": as "layer" with the draw in a launch of its own (the last layer's launch draws by default)
-        mode = os.environ.get("MPNN_SAMPLE_LAUNCHES", "layer")
+        # default "run": the whole level loop in ONE library call (mpnn_decode_run: the "layer" mode's launches issued
+        # from C; the Python loop below costs ~11 us of host time per launch, more than the kernels take)
+        mode = os.environ.get("MPNN_SAMPLE_LAUNCHES", "run")
+        run_in_c = mode in ("run", "run/head")
+        if run_in_c:
+            mode = "layer" if mode == "run" else "layer/head"
         head_fused = mode == "layer" and plans[-1][2][37] == 0   # the last decoder layer has no projections
         if mode == "layer/head":
             mode = "layer"
@@ -830,7 +859,17 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
         list_ptr = perm.data_ptr()
         start = 0
         rc = 0
-        for cnt_l in counts:
+        if run_in_c and mode == "layer" and K <= 48 and plans[-1][2][37] == 0:
+            c_counts = (ctypes.c_int * len(counts))(*counts)
+            call("mpnn_decode_run", ptr(enc["hE"]), ptr(PQenc), PQenc.shape[1], ptr(rank), ptr(enc["E_idx32"]),
+                 ptr(mask_s), ptr(enc["edge_mask"]), list_ptr, c_counts, len(counts), N, L, K, float(K), layers, n_dec,
+                 ptr(pw.Wlogit), ptr(pw.blogit), ptr(lb), pw.n_letters, float(temperature),
+                 int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(designable), ptr(S_in), ptr(S_out), ptr(log_probs), ptr(pw.TS),
+                 pw.TS.shape[1], 1 if head_fused else 0, st)
+            counts_loop = []
+        else:
+            counts_loop = counts
+        for cnt_l in counts_loop:
             p_nodes = list_ptr + 4 * start
             start += cnt_l
             if mode == "level":

@@ -218,12 +218,13 @@ class ProteinMPNN(nn.Module):
         return self
 
     def check_numerics(self):
-        """Wait for the calls issued so far and raise RuntimeError if one of them produced inf / NaN log-probs (an
-        operand left the f16-split range of the matrix-pipe kernels, include/mpnn_hip.h OPERAND RANGE).  Without this
-        call the same error surfaces, one call late and without any host synchronisation, at the next forward."""
+        """Wait for the calls issued so far and raise RuntimeError if any of them (named by its call number) produced
+        inf / NaN log-probs (an operand left the f16-split range of the matrix-pipe kernels, include/mpnn_hip.h OPERAND
+        RANGE).  Without this call a bad call is only WARNED about (engine.NumericsWarning, with its call number), one
+        call late and without any host synchronisation, when the model is called next - that call runs as usual."""
         g = self.__dict__.get("_numerics")
         if g is not None:
-            g.poll(block=True)
+            g.check()
         return self
 
     def sample(self, X, mask, chain_M, residue_idx, chain_encoding_all, S_true=None, n_samples=1, temperature=0.1,

@@ -231,12 +231,11 @@ def _packed(model) -> _Packed:
     pw = model.__dict__.get("_packed")
     if pw is None or pw.key != PackedWeights.make_key(model):
         check_weight_range(model)
-        saved = _lib._suffix  # derived tables are always built with fp32-class products
-        _lib._suffix = ""
+        saved = _lib.set_precision("fp32")  # derived tables are always built with fp32-class products
         try:
             pw = _Packed(model)
         finally:
-            _lib._suffix = saved
+            _lib.set_precision(saved)
         model.__dict__["_packed"] = pw
     return pw
 
@@ -352,6 +351,14 @@ class ProteinMPNN(nn.Module):
             return out
         finally:
             _lib.set_precision("fp32")
+
+    def check_numerics(self):
+        """As mpnn_amd.ProteinMPNN.check_numerics: wait for the calls issued so far and raise RuntimeError naming every
+        call that produced inf / NaN log-probs; without it a bad call is only warned about when the model is called next."""
+        g = self.__dict__.get("_numerics")
+        if g is not None:
+            g.check()
+        return self
 
     def _forward(self, x, S, mask, chain_mask_all, residue_idx, chain_encoding_all, batch, decoding_order):
         dev = x.device

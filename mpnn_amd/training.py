@@ -682,7 +682,8 @@ def make_optimizer(model, lr=1e-3, weight_decay=1e-2, total_steps=None, max_grad
     """AdamW and, when `total_steps` is given, the reference's schedule (train.py:217-222): linear warm-up from 1e-8 over
     the first 1 % of the steps, then cosine annealing to 0.  On a ROCm device the optimizer is the in-tree multi-tensor
     kernel (`mpnn_amd.optim.AdamW`: all 1.66 M parameters in three launches, gradient clipping of train.py:389-390
-    folded in when `max_grad_norm` > 0); a model on the CPU gets torch's.  -> (optimizer, scheduler or None)."""
+    folded in when `max_grad_norm` > 0); a model with any parameter off the device gets torch.optim.AdamW (train_step
+    then clips with torch.nn.utils.clip_grad_norm_).  -> (optimizer, scheduler or None)."""
     from torch.optim.lr_scheduler import CosineAnnealingLR, LinearLR, SequentialLR
     if all(p.is_cuda for p in model.parameters()):
         from .optim import AdamW
@@ -702,9 +703,11 @@ def make_optimizer(model, lr=1e-3, weight_decay=1e-2, total_steps=None, max_grad
 
 
 def train_step(model, optimizer, batch, world_size=1, fix_order=None, fix_backbone_noise=None, scheduler=None,
-               max_grad_norm=0.0):
+               max_grad_norm=None):
     """One optimisation step (reference train.py:376-395): forward, smoothed loss, backward, (gradient all-reduce),
-    optional gradient-norm clipping (:389-390), optimizer and scheduler step."""
+    optional gradient-norm clipping (:389-390), optimizer and scheduler step.  max_grad_norm: None keeps what the
+    in-tree optimizer was built with (no clipping for other optimizers); a number sets it for this and later steps,
+    0 switching the clip off."""
     from . import distributed
     X, S, mask, chain_M, residue_idx, chain_enc = batch
     optimizer.zero_grad(set_to_none=True)
@@ -713,12 +716,16 @@ def train_step(model, optimizer, batch, world_size=1, fix_order=None, fix_backbo
     _, loss = loss_smoothed_fused(S, log_probs, mask_for_loss)
     loss.backward()
     distributed.allreduce_gradients(model.parameters(), world_size)  # no-op for a single rank
-    if max_grad_norm and max_grad_norm > 0.0:
-        from . import optim
-        if isinstance(optimizer, optim.AdamW):
-            optimizer.max_grad_norm = float(max_grad_norm)      # clipped inside the update pass
-        else:
-            optim.clip_grad_norm_(list(model.parameters()), max_grad_norm)
+    from . import optim
+    if isinstance(optimizer, optim.AdamW):
+        if max_grad_norm is not None:
+            optimizer.max_grad_norm = float(max_grad_norm)      # clipped inside the update pass; 0 switches it off again
+    elif max_grad_norm is not None and max_grad_norm > 0.0:
+        params = [p for p in model.parameters() if p.grad is not None]
+        if all(p.grad.is_cuda and p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in params):
+            optim.clip_grad_norm_(params, max_grad_norm)
+        else:   # gradients the HIP kernels do not take (CPU, non-contiguous, other dtypes): torch's own clip
+            torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
     optimizer.step()
     if scheduler is not None:
         scheduler.step()

@@ -65,6 +65,58 @@ def test_clip_grad_norm_matches_torch():
             assert torch.allclose(p.grad.cpu(), q.grad, rtol=2e-6, atol=1e-9)
 
 
+def test_clip_with_non_finite_gradients_matches_torch():
+    """One NaN gradient element makes the norm NaN: torch's clip then turns EVERY gradient into NaN (clamp(nan, max=1)
+    is nan) - an obvious failure - and so must the kernels, in the stand-alone clip and inside the AdamW pass.  One
+    infinite element gives coefficient 0 in both: finite gradients are zeroed, the infinite one becomes NaN."""
+    from mpnn_amd.optim import AdamW, clip_grad_norm_
+
+    for poison in (float("nan"), float("inf")):
+        ours = [torch.nn.Parameter(p.clone().cuda()) for p in _params(1)]
+        ref = [torch.nn.Parameter(p.clone()) for p in _params(1)]
+        for p, q, g in zip(ours, ref, _params(2)):
+            p.grad, q.grad = g.clone().cuda(), g.clone()
+        ours[5].grad.view(-1)[3] = poison
+        ref[5].grad.view(-1)[3] = poison
+        clip_grad_norm_(ours, 0.7)
+        torch.nn.utils.clip_grad_norm_(ref, 0.7)
+        for p, q in zip(ours, ref):
+            assert torch.equal(torch.isnan(p.grad.cpu()), torch.isnan(q.grad))
+            assert torch.allclose(p.grad.cpu(), q.grad, rtol=2e-6, atol=1e-9, equal_nan=True)
+        # folded into the update: the parameters end up NaN exactly where torch's do
+        ours = [torch.nn.Parameter(p.clone().cuda()) for p in _params(1)]
+        ref = [torch.nn.Parameter(p.clone()) for p in _params(1)]
+        for p, q, g in zip(ours, ref, _params(2)):
+            p.grad, q.grad = g.clone().cuda(), g.clone()
+        ours[5].grad.view(-1)[3] = poison
+        ref[5].grad.view(-1)[3] = poison
+        opt, opt_ref = AdamW(ours, lr=1e-3, max_grad_norm=0.7), torch.optim.AdamW(ref, lr=1e-3)
+        torch.nn.utils.clip_grad_norm_(ref, 0.7)
+        opt.step()
+        opt_ref.step()
+        for p, q in zip(ours, ref):
+            assert torch.equal(torch.isnan(p.detach().cpu()), torch.isnan(q.detach())), poison
+
+
+def test_train_step_max_grad_norm_is_per_call():
+    """train_step(max_grad_norm=x) sets the in-tree optimizer's clip for that step; a later 0 switches it off again
+    (it used to stick), None leaves the optimizer's own setting."""
+    import mpnn_amd
+    from mpnn_amd import training
+    from mpnn_amd.synthetic import synthetic_batch
+
+    model = mpnn_amd.ProteinMPNN(k_neighbors=16, augment_eps=0.0, dropout=0.0).train().cuda()
+    opt, _ = training.make_optimizer(model, lr=1e-3, max_grad_norm=0.5)
+    b = synthetic_batch(B=1, L=32, seed=3, device="cuda")
+    batch = (b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
+    training.train_step(model, opt, batch, fix_order=b["fix_order"])
+    assert opt.max_grad_norm == 0.5
+    training.train_step(model, opt, batch, fix_order=b["fix_order"], max_grad_norm=1.0)
+    assert opt.max_grad_norm == 1.0
+    training.train_step(model, opt, batch, fix_order=b["fix_order"], max_grad_norm=0.0)
+    assert opt.max_grad_norm == 0.0
+
+
 def test_train_step_uses_the_in_tree_optimizer():
     import mpnn_amd
     from mpnn_amd import optim, training

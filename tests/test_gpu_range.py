@@ -66,18 +66,58 @@ def test_weight_beyond_f16_range_is_refused_when_packed():
         run_hip(model, rec, keep=False)
 
 
+def _overflowing_model():
+    model = _scale(build_model(dict(k_neighbors=16)), lambda n: "dense.W_in.weight" in n or "W1.weight" in n, 2.0e3)
+    return _scale(model, lambda n: "dense.W_out.weight" in n or n.endswith("W2.weight"), 2.0e3)
+
+
 def test_activation_overflow_is_reported_not_silent():
     """Weights in range, activations not (FFN output weights x 3e4 push h_V past 131008 before the LayerNorm): the
-    outputs are inf / NaN, and the wrapper says so - at check_numerics(), or one call late at the next forward."""
-    model = _scale(build_model(dict(k_neighbors=16)), lambda n: "dense.W_in.weight" in n or "W1.weight" in n, 2.0e3)
-    model = _scale(model, lambda n: "dense.W_out.weight" in n or n.endswith("W2.weight"), 2.0e3)
+    outputs are inf / NaN, and the wrapper says so - check_numerics() raises, naming the call by its number."""
+    model = _overflowing_model()
     rec = _batch()
     out = run_hip(model, rec, keep=False)
     assert not bool(torch.isfinite(out).all()), "this model must overflow the f16-split range"
-    with pytest.raises(RuntimeError, match="inf / NaN"):
+    with pytest.raises(RuntimeError, match=r"call #1 .*inf / NaN"):
         model.check_numerics()
     model.check_numerics()                       # reported once, then clean
-    run_hip(model, rec, keep=False)
-    torch.cuda.synchronize()
-    with pytest.raises(RuntimeError, match="inf / NaN"):
-        run_hip(model, rec, keep=False)          # the previous call's overflow surfaces here without a blocking wait
+
+
+def test_bad_call_does_not_abort_the_next_good_call():
+    """A serving loop: request 1 overflows, request 2 is fine.  The overflow of call #1 surfaces at call #2 WITHOUT a
+    blocking wait - as a NumericsWarning that names call #1 - and call #2 still runs and returns its (finite, correct)
+    result; check_numerics() then raises once for #1 only."""
+    import warnings
+
+    from mpnn_amd.engine import NumericsWarning
+
+    kw = dict(k_neighbors=16)
+    model = build_model(kw)
+    rec = _batch()
+    good = run_hip(model, rec, keep=False)                      # call #1: fine
+    state = {n: p.detach().clone() for n, p in model.named_parameters()}
+    bad_model = _overflowing_model()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(dict(bad_model.named_parameters())[n].to(p.device))
+    out = run_hip(model, rec, keep=False)                       # call #2: overflows
+    assert not bool(torch.isfinite(out).all())
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(state[n])
+    torch.cuda.synchronize()                                    # (so that the non-blocking look at call #2 sees it)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        again = run_hip(model, rec, keep=False)                 # call #3: fine, and must not be aborted
+    msgs = [str(w.message) for w in caught if issubclass(w.category, NumericsWarning)]
+    assert len(msgs) == 1 and "call #2" in msgs[0], msgs
+    assert torch.equal(again, good)
+    with pytest.raises(RuntimeError, match=r"call #2 "):
+        model.check_numerics()
+    model.check_numerics()
+
+
+def test_sparse_model_has_check_numerics():
+    from mpnn_amd import sparse
+
+    assert callable(getattr(sparse.ProteinMPNN, "check_numerics", None))

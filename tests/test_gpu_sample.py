@@ -160,13 +160,17 @@ def test_launch_modes_agree(monkeypatch):
     args = (b["X"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
     for n_samples in (2, 40):
         outs = {}
-        for mode in ("layer", "layer/head", "layer+draw", "level", "split"):
+        for mode in ("run", "run/head", "layer", "layer/head", "layer+draw", "level", "split"):
             monkeypatch.setenv("MPNN_SAMPLE_LAUNCHES", mode)
             outs[mode] = model.sample(*args, S_true=b["S"], n_samples=n_samples, temperature=0.3, seed=7)
         # the default ("layer": the last layer's launch also draws) against the draw in a launch of its own: the same
         # arithmetic on the same values, bit for bit (neighbour sums meet in LDS in both)
         assert torch.equal(outs["layer"]["S"], outs["layer/head"]["S"])
         assert float((outs["layer"]["log_probs"] - outs["layer/head"]["log_probs"]).abs().max()) <= 1e-5
+        # the default ("run": mpnn_decode_run issues the "layer" mode's launches from C) and its separate-head form
+        for other in ("run", "run/head"):
+            assert torch.equal(outs["layer"]["S"], outs[other]["S"]), other
+            assert float((outs["layer"]["log_probs"] - outs[other]["log_probs"]).abs().max()) <= 1e-5, other
         for other in ("layer+draw", "level", "split"):
             same = (outs["layer"]["S"] == outs[other]["S"]).float().mean()
             assert float(same) > 0.99, other  # a draw can flip where u lands within an ulp of a CDF step

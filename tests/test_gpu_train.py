@@ -76,6 +76,8 @@ CASES = {
     "k64_L80": (dict(k_neighbors=64), dict(B=2, L=80, seed=11, lengths=[80, 70], n_chains=2, design_fraction=0.5)),
     "k56_L96_vc": (dict(k_neighbors=56, use_virtual_center=True),
                    dict(B=2, L=96, seed=12, lengths=[96, 61], n_chains=2, design_fraction=0.6)),
+    # BASELINE configs[2]'s protein length: hub residues with hundreds of inverse-list entries, L^2 slot maps
+    "k48_L512": (dict(k_neighbors=48), dict(B=2, L=512, seed=14, lengths=[512, 400], n_chains=2, design_fraction=0.6)),
 }
 
 
@@ -92,6 +94,41 @@ def test_gradients_vs_oracle_autograd(name):
     assert float((lp - olp).abs().max()) <= 1e-4
     worst = compare_grads(grads, ograds)
     print(f"{name}: loss {loss:.6f}, worst relative gradient error {worst[0]:.2e} ({worst[1]})")
+
+
+def test_gradients_at_configs2_size():
+    """BASELINE configs[2] at size: ONE step's batch of 20 x 512 residues (ragged, two chains each).  The weight-gradient
+    kernels' split-K partition over ~10 k residues, their partial-sum workspace, the per-wave power-of-two gradient
+    scaling and the B L^2 inverse-list slot map only show at this size.  Proteins are independent and the loss
+    normaliser is a constant (train.py:72), so the oracle's loss and gradients are accumulated over chunks of four
+    proteins (bounded host memory); the HIP path sees the whole batch at once."""
+    from mpnn_amd.synthetic import synthetic_batch
+    from oracle import mpnn_oracle as orc
+
+    kw = dict(k_neighbors=48)
+    B, L = 20, 512
+    lengths = [512, 480, 512, 350, 512, 505, 300, 512, 444, 512, 512, 391, 512, 470, 512, 333, 512, 512, 420, 512]
+    b = synthetic_batch(B=B, L=L, seed=33, lengths=lengths, n_chains=2, design_fraction=0.7)
+    model = build(kw)
+    loss, lp, grads = hip_loss_and_grads(model, b)
+
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    oloss = 0.0
+    keys = ("X", "S", "mask", "chain_M", "residue_idx", "chain_encoding_all", "fix_order")
+    for r0 in range(0, B, 4):
+        c = {k: b[k][r0:r0 + 4] for k in keys}
+        olp = orc.forward(sd, oracle_cfg(kw), c["X"], c["S"], c["mask"], c["chain_M"], c["residue_idx"],
+                          c["chain_encoding_all"], fix_order=c["fix_order"], formulation="edge")
+        _, l_ = orc.loss_smoothed(c["S"], olp, c["mask"] * c["chain_M"])
+        l_.backward()                      # .grad accumulates over the chunks
+        oloss += l_.item()
+        m = c["mask"].bool()
+        err = (lp[r0:r0 + 4] - olp.detach()).abs()[m]
+        assert bool((err <= 1e-5 + 1e-4 * olp.detach().abs()[m]).all()), (r0, err.max().item())
+    ograds = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items() if v.requires_grad}
+    assert abs(loss - oloss) <= 1e-5 * abs(oloss), (loss, oloss)
+    worst = compare_grads(grads, ograds)
+    print(f"20 x 512: loss {loss:.6f}, worst relative gradient error {worst[0]:.2e} ({worst[1]})")
 
 
 def test_gradients_vs_reference_golden():
