@@ -219,12 +219,15 @@ int mpnn_node_update(const float* hV_in, const float* gsum, const float* cnt, fl
 /* Optimizer step of the reference's training loop (train.py:217 torch.optim.AdamW(lr, weight_decay=1e-2), :389-393
  * clip_grad_norm_ then optimizer.step) for ALL parameter tensors in one launch per 48 tensors.
  * params / grads / exp_avg / exp_avg_sq / numel are HOST arrays of n device pointers / element counts (fp32 tensors).
- *   mpnn_grad_sumsq: sumsq[0] += sum of squares of every gradient element (zero sumsq first; device scalar).
+ *   mpnn_grad_sumsq: sumsq[0] = sum of squares of every gradient element (device scalar).  Per-workgroup partials go
+ *     to `workspace` and are added in a fixed tree (no atomics: the clip coefficient, hence the update, is the same on
+ *     every run); workspace_floats >= sum over groups of 48 tensors of ceil(largest numel / 2048) * tensors in group.
  *   mpnn_grad_scale: grads *= min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))       (torch.nn.utils.clip_grad_norm_)
  *   mpnn_adamw_step: torch.optim.AdamW's update (decoupled weight decay, bias correction for `step` >= 1, no amsgrad);
  *     when grad_sumsq != NULL and max_norm > 0 the clip coefficient above is applied to the gradients on the fly, so
  *     clipping costs no extra pass over them and nothing synchronises with the host. */
-int mpnn_grad_sumsq(int n, const float* const* grads, const int* numel, float* sumsq, void* stream);
+int mpnn_grad_sumsq(int n, const float* const* grads, const int* numel, float* sumsq, float* workspace,
+                    int workspace_floats, void* stream);
 int mpnn_grad_scale(int n, float* const* grads, const int* numel, const float* sumsq, float max_norm, void* stream);
 int mpnn_adamw_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,
                     float* const* exp_avg_sq, const int* numel, float lr, float beta1, float beta2, float eps,
@@ -296,12 +299,15 @@ int mpnn_message_bwd(int dec, const float* dgsum, const float* a1_frag, const fl
                      float* amax2, void* stream);
 
 /* Backward of the edge update: LayerNorm', W13^T, W12^T, W11b^T; dln[0:128] += d ln_w, dln[128:256] += d ln_b.
- * dE_frag may alias dy_frag.  amax3[0..2] (zero them first) receive max |dz|, |da2|, |da1 rows|. */
+ * dE_frag may alias dy_frag.  amax3[0..2] (zero them first) receive max |dz|, |da2|, |da1 rows|.
+ * workspace: >= 256 floats per workgroup (one workgroup per CU at most: 65536 floats always suffice) for the
+ * LayerNorm-parameter partial sums, which a second small launch adds in a fixed order - no floating-point atomics
+ * anywhere in the backward pass, every gradient is bit-identical from run to run. */
 int mpnn_enc_edge_update_bwd(const float* dy_frag, const float* z_frag, const float* a2_frag, const float* a1_frag,
                              const float* ln_w, const float* W13T_packed, const float* W12T_packed,
                              const float* W11bT_packed, int B, int L, int K, float* dz_frag, float* da2_frag,
                              float* da1_rows, float* dP, float* dE_frag, float* dln, float* amax3, float p_drop,
-                             uint32_t drop_seed, void* stream);
+                             uint32_t drop_seed, float* workspace, int workspace_floats, void* stream);
 
 /* dW[fo][fi] += sum_edges A[e][fo] * f(B[e][fi]), dbias[fo] += sum_edges A[e][fo]  (the nn.Linear weight / bias
  * gradients of one per-edge 128x128 layer).  A: fragment layout, or rows when a_rows != 0; B: fragment layout,
@@ -314,22 +320,29 @@ int mpnn_enc_edge_update_bwd(const float* dy_frag, const float* z_frag, const fl
 int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax, const float* B_frag, int b_gelu, int n_nodes,
                     int K, float* dW, float* dbias, float* workspace, int workspace_floats, void* stream);
 
-/* Gradient of the neighbour gather h[E_idx]: outA[j] += sum of rows[inv_row[m]] for m in [inv_ptr[j], inv_ptr[j+1]),
+/* Gradient of the neighbour gather h[E_idx]: outA[j] = sum of rows[inv_row[m]] for m in [inv_ptr[j], inv_ptr[j+1]),
  * split between outA (sel[m] == 0) and outB (sel[m] != 0) when sel is given (decoder: which block the edge read).
- * Work unit = a chunk of <= 32 list entries: chunk_ptr[j] = sum_{i<j} ceil(degree_i / 32) (n_nodes + 1 entries),
- * max_chunks >= chunk_ptr[n_nodes] (n_edges / 32 + n_nodes always suffices).  Outputs are accumulated with atomics:
- * zero them first. */
+ * Work unit = a chunk of <= 64 list entries: node j owns max(1, ceil(degree_j / 64)) chunks, chunk_ptr [n_nodes + 1]
+ * their offsets, chunk_node[c] the node of chunk c, max_chunks >= chunk_ptr[n_nodes] (n_edges / 64 + n_nodes always
+ * suffices).  Every output row is WRITTEN (no zero fill needed), in list order with a fixed summation tree: no atomics,
+ * bit-identical from run to run.  partials: device scratch of max_chunks * 256 floats (the partial sums of the nodes
+ * that own several chunks, added in chunk order by a second small launch). */
 int mpnn_gather_rows(const float* rows, const int32_t* inv_ptr, const int32_t* inv_row, const unsigned char* sel,
-                     const int32_t* chunk_ptr, int n_nodes, int max_chunks, float* outA, float* outB, void* stream);
+                     const int32_t* chunk_ptr, const int32_t* chunk_node, int n_nodes, int max_chunks, float* outA,
+                     float* outB, float* partials, void* stream);
 
 /* Inverse neighbour lists for mpnn_gather_rows (the index side of the autograd of gather_nodes, :19-26, which the
  * reference leaves to torch's scatter-add): inv_row [B*L*K] = edge ids (i * Kp + k, Kp = 16 ceil(K/16)) grouped by the
  * node j = E_idx[i][k] they gather from and ordered by (i, k) inside a group - the order of a stable sort, the same
- * on every run; inv_ptr [B*L + 1] the group offsets, chunk_ptr [B*L + 1] the offsets in chunks of <= 32 entries.
- * E_idx32 [B*L, Kp] as mpnn_knn_topk writes it (ids local to the protein, a residue's K neighbours distinct).
+ * on every run; inv_ptr [B*L + 1] the group offsets, chunk_ptr [B*L + 1] / chunk_node [B*L*K / 64 + B*L] the chunk
+ * table of mpnn_gather_rows.
+ * E_idx32 [B*L, Kp] as mpnn_knn_topk writes it (ids local to the protein, a residue's K neighbours distinct).  The
+ * construction keeps ONE edge per (target, centre) pair: a residue that lists a neighbour twice, or an id outside
+ * [0, L), loses an edge - status (optional device word) is then set to 1, else 0; callers with lists of unknown origin
+ * check it and fall back to a sort (mpnn_amd.training.Graph does).
  * slot_map: B*L*L bytes of device scratch.  1 <= K <= min(64, L). */
 int mpnn_inverse_lists(const int32_t* E_idx32, int B, int L, int K, unsigned char* slot_map, int32_t* inv_ptr,
-                       int32_t* chunk_ptr, int32_t* inv_row, void* stream);
+                       int32_t* chunk_ptr, int32_t* chunk_node, int32_t* inv_row, int32_t* status, void* stream);
 /* sel [B*L*K] for mpnn_gather_rows in the decoder (:507-525): 1 where the gathering residue i does not come after its
  * neighbour j in the decoding order (rank[i] <= rank[j]: the edge read the encoder block), in list order. */
 int mpnn_inverse_sel(const int32_t* rank, const int32_t* inv_ptr, const int32_t* inv_row, int n_nodes, int K,
@@ -344,9 +357,11 @@ int mpnn_edge_features_train(const float* atoms, const int32_t* E_idx32, const i
                              float* hE_frag, void* stream);
 
 /* Featurizer backward: dE = W_e^T dhE0, dE0 = LayerNorm'(dE; E0).  WeT_packed = mpnn_pack_linear_split(W_e^T).
- * dln[0:128] += d norm_edges.weight, dln[128:256] += d norm_edges.bias; amax2 (zeroed) <- max |dhE0|, max |dE0|. */
+ * dln[0:128] += d norm_edges.weight, dln[128:256] += d norm_edges.bias; amax2 (zeroed) <- max |dhE0|, max |dE0|.
+ * workspace as for mpnn_enc_edge_update_bwd (256 floats per workgroup). */
 int mpnn_edge_features_bwd(const float* dhE_frag, const float* E0_frag, const float* ln_w, const float* WeT_packed,
-                           int B, int L, int K, float* dE0_frag, float* dln, float* amax2, void* stream);
+                           int B, int L, int K, float* dE0_frag, float* dln, float* amax2, float* workspace,
+                           int workspace_floats, void* stream);
 
 /* The edge_embedding layer's raw inputs in the fragment layout, 128 features per chunk, chunks back to back:
  * feature 16 p + r (p < n_atoms^2) = RBF r of atom pair p (:334-347); features 16 n_atoms^2 + d = one-hot of the
@@ -371,13 +386,15 @@ int mpnn_node_update_train(const float* hV_in, const float* gsum, const float* c
  * *T_packed = mpnn_pack_linear_split of the transposed matrices (WoutT: the four 128-column blocks of W_out transposed,
  * WinT: the four 128-row blocks of W_in transposed, consecutive).  Outputs: d_hV_in, d_gsum, and the operands of the
  * weight gradients (mpnn_node_wgrad): x1 [n,128], hid = gelu(a) [n,512], d_a [n,512], d_o [n,128], d_dh [n,128];
- * dvec640 (zero it first) += d ln1_w | d ln1_b | d ln2_w | d ln2_b | d b3. */
+ * dvec640 (zero it first) += d ln1_w | d ln1_b | d ln2_w | d ln2_b | d b3 (per-workgroup partials in `workspace`,
+ * >= 640 floats per 64 nodes, added in a fixed order by a second small launch). */
 int mpnn_node_update_bwd(const float* dY, const float* dPQ_blocks, const float* x1pre, const float* a_pre,
                          const float* x2pre, const float* cnt, float cnt_const, const float* mask, const float* ln1_w,
                          const float* ln1_b, const float* ln2_w, float scale, const float* WprojT_packed, int nproj,
                          const float* WoutT_packed, const float* WinT_packed, const float* W3T_packed, int n_nodes,
                          float* d_hV_in, float* d_gsum, float* x1, float* hid, float* d_a, float* d_o, float* d_dh,
-                         float* dvec640, float p_drop, uint32_t drop_seed, void* stream);
+                         float* dvec640, float p_drop, uint32_t drop_seed, float* workspace, int workspace_floats,
+                         void* stream);
 
 /* mpnn_pack_linear_split for n 128x128 blocks in one launch per 16 blocks: block b is read at blocks[b] with row
  * stride ld[b] (out[o][i] = W[o * ld + i]), or transposed (out[o][i] = W[i * ld + o]) when transposed[b] != 0, and
@@ -422,7 +439,8 @@ int mpnn_decode_levels(const int64_t* order, const int32_t* rank, const int32_t*
 
 /* mpnn_dec_message for the residues in node_list: hE / E_idx32 / edge_mask / PVenc are indexed with
  * (residue % enc_nodes); P, RowA, rank, mask, gsum with the residue id.  One wave per (residue, 16-neighbour tile);
- * the partial sums are ADDED to gsum with atomics: the listed gsum rows must be zero on entry. */
+ * gsum is [residue][4][128]: tile c of a residue stores its sums to gsum[residue][c] (plain stores, no atomics;
+ * mpnn_node_update_subset adds the ceil(K/16) tiles in order). */
 int mpnn_dec_message_subset(const float* hE_frag, const float* P, int ldp, int offP, const float* RowA, int lda,
                             int offA, const float* PVenc, int ldenc, int offEnc, const int32_t* rank,
                             const int32_t* E_idx32, const float* mask, const float* edge_mask, const float* W1b_packed,
@@ -460,9 +478,9 @@ int mpnn_dec_layer_sample_subset(const float* hE_frag, const float* P, int ldp, 
                                  const float* TS, int ld_ts, int n_layers, float* const* A_rows, const int* A_ld,
                                  const int* A_off, void* stream);
 
-/* mpnn_node_update (do_update = 1, cnt = cnt_const, no table add) for the residues in node_list; sets the gsum rows it
- * has read back to zero, ready for the next level's accumulation. */
-int mpnn_node_update_subset(const float* hV_in, float* gsum, float cnt_const, const float* mask,
+/* mpnn_node_update (do_update = 1, cnt = cnt_const, no table add) for the residues in node_list; gsum [residue][4][128]
+ * as mpnn_dec_message_subset writes it, n_tiles = ceil(K/16) of its tiles are added, in tile order. */
+int mpnn_node_update_subset(const float* hV_in, const float* gsum, int n_tiles, float cnt_const, const float* mask,
                             const float* W3_packed, const float* b3, const float* ln1_w, const float* ln1_b,
                             const float* Win_packed, const float* b_in, const float* Wout_packed, const float* b_out,
                             const float* ln2_w, const float* ln2_b, float scale, const float* Wproj_packed,
@@ -579,7 +597,7 @@ int mpnn_dec_layer_sample_subset_f16(const float* hE_frag, const float* P, int l
                                  const float* TS, int ld_ts, int n_layers, float* const* A_rows, const int* A_ld,
                                  const int* A_off, void* stream);
 
-int mpnn_node_update_subset_f16(const float* hV_in, float* gsum, float cnt_const, const float* mask,
+int mpnn_node_update_subset_f16(const float* hV_in, const float* gsum, int n_tiles, float cnt_const, const float* mask,
                             const float* W3_packed, const float* b3, const float* ln1_w, const float* ln1_b,
                             const float* Win_packed, const float* b_in, const float* Wout_packed, const float* b_out,
                             const float* ln2_w, const float* ln2_b, float scale, const float* Wproj_packed,
@@ -595,15 +613,19 @@ int mpnn_node_wgrad_batch(int n_jobs, const float* const* dY, const int* ldy, co
 /* ---- output head backward and loss ---------------------------------------------------------
  * Backward of mpnn_logits_log_softmax (reference model_utils.py :527-528): d_logits = d_log_probs - exp(log_probs) *
  * rowsum(d_log_probs); d_hV [n_nodes,128] = d_logits W_out; dW [n_letters,128] += d_logits^T hV; db [n_letters] +=
- * column sums (dW / db accumulate: zero them first; db may be NULL).  W_out is the nn.Linear weight, row-major. */
+ * column sums (dW / db accumulate: zero them first; db may be NULL).  W_out is the nn.Linear weight, row-major.
+ * workspace: >= 4128 floats per 64 nodes (per-workgroup partials of dW | db, added in a fixed order). */
 int mpnn_logits_log_softmax_bwd(const float* d_log_probs, const float* log_probs, const float* hV, const float* W_out,
-                                int n_letters, int n_nodes, float* d_hV, float* dW, float* db, void* stream);
+                                int n_letters, int n_nodes, float* d_hV, float* dW, float* db, float* workspace,
+                                int workspace_floats, void* stream);
 
 /* loss_smoothed of the reference's training loop (train.py:63-73): t = (one_hot(S) + weight / n_letters) normalised,
- * loss [n_nodes] = -sum_a t log_probs, loss_sum += scale * sum_n loss mask (scale = 1/2000 there; zero loss_sum first),
- * and, when d_log_probs is given, the gradient of loss_sum: -t mask scale. */
+ * loss [n_nodes] = -sum_a t log_probs, loss_sum = scale * sum_n loss mask (scale = 1/2000 there),
+ * and, when d_log_probs is given, the gradient of loss_sum: -t mask scale.
+ * workspace: >= one float per 256 nodes (per-workgroup partial sums, added in a fixed tree). */
 int mpnn_loss_smoothed(const float* log_probs, const int64_t* S, const float* mask, int n_nodes, int n_letters,
-                       float weight, float scale, float* loss, float* loss_sum, float* d_log_probs, void* stream);
+                       float weight, float scale, float* loss, float* loss_sum, float* d_log_probs, float* workspace,
+                       int workspace_floats, void* stream);
 
 /* ---- batch assembly ----------------------------------------------------------------------
  * Padded model inputs for B structures out of a flat shard in device memory, i.e. what the reference's host function

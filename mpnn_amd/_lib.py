@@ -63,13 +63,13 @@ SIGNATURES = {
     "mpnn_message_train": [_I] + [_P] * 11 + [_I] * 3 + [_P] * 5,
     "mpnn_enc_edge_update_train": [_P] * 11 + [_I] * 3 + [_P] * 4 + [_F, ctypes.c_uint32, _P],
     "mpnn_message_bwd": [_I] + [_P] * 8 + [_I] * 3 + [_P] * 4 + [_I, _P, _P],
-    "mpnn_enc_edge_update_bwd": [_P] * 8 + [_I] * 3 + [_P] * 7 + [_F, ctypes.c_uint32, _P],
+    "mpnn_enc_edge_update_bwd": [_P] * 8 + [_I] * 3 + [_P] * 7 + [_F, ctypes.c_uint32, _P, _I, _P],
     "mpnn_edge_wgrad": [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P],
-    "mpnn_gather_rows": [_P] * 5 + [_I, _I] + [_P] * 3,
-    "mpnn_inverse_lists": [_P, _I, _I, _I, _P, _P, _P, _P, _P],
+    "mpnn_gather_rows": [_P] * 6 + [_I, _I] + [_P] * 4,
+    "mpnn_inverse_lists": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "mpnn_inverse_sel": [_P, _P, _P, _I, _I, _P, _P],
     "mpnn_edge_features_train": [_P] * 11 + [_I, _I, _I, _I, _P, _P, _P, _P],
-    "mpnn_edge_features_bwd": [_P] * 4 + [_I] * 3 + [_P] * 4,
+    "mpnn_edge_features_bwd": [_P] * 4 + [_I] * 3 + [_P] * 4 + [_I, _P],
     "mpnn_feature_chunks": [_P] * 5 + [_I] * 4 + [_P, _P],
     # autoregressive sampling
     "mpnn_decode_levels": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
@@ -78,20 +78,21 @@ SIGNATURES = {
                              [_F, _P, _P, _I, _P, _P, _P],
     "mpnn_dec_layer_sample_subset": [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I] + [_P] * 8 + [_I] * 4 + [_P, _F] + [_P] * 10 +
                                     [_F, _P] + [_P, _P, _P, _I, _F, ctypes.c_uint64] + [_P] * 5 + [_I, _I, _P, _P, _P, _P],
-    "mpnn_node_update_subset": [_P, _P, _F, _P] + [_P] * 10 + [_F, _P, _P, _I, _P, _I, _P, _P, _P],
+    "mpnn_node_update_subset": [_P, _P, _I, _F, _P] + [_P] * 10 + [_F, _P, _P, _I, _P, _I, _P, _P, _P],
     "mpnn_sample_subset": [_P, _P, _P, _P, _I, _P, _I, _F, ctypes.c_uint64, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "mpnn_node_update_train": [_P, _P, _P, _F] + [_P] * 11 + [_F, _P, _P, _I, _I] + [_P] * 5 + [_F, ctypes.c_uint32, _P],
-    "mpnn_node_update_bwd": [_P] * 6 + [_F] + [_P] * 4 + [_F, _P, _I, _P, _P, _P, _I] + [_P] * 8 + [_F, ctypes.c_uint32, _P],
+    "mpnn_node_update_bwd": [_P] * 6 + [_F] + [_P] * 4 + [_F, _P, _I, _P, _P, _P, _I] + [_P] * 8 +
+                            [_F, ctypes.c_uint32, _P, _I, _P],
     "mpnn_node_wgrad_batch": [_I] + [_P] * 9 + [_I, _P, _I, _P],
     "mpnn_pack_blocks": [_P, _P, _P, _I, _P, _P],
-    "mpnn_logits_log_softmax_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
-    "mpnn_loss_smoothed": [_P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _P],
+    "mpnn_logits_log_softmax_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
+    "mpnn_loss_smoothed": [_P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _P, _I, _P],
     "mpnn_assemble_batch": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "mpnn_mask_self": [_P, _I, _I, _P, _P],
     "mpnn_node_wgrad": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P],
     "mpnn_gather_indexed": [_P, _P, ctypes.c_longlong, _I, ctypes.c_longlong, _I, _P, _I, _I, _P],
     "mpnn_positional_encodings": [_P, _P, ctypes.c_longlong, _I, _P, _I, _P, _P],
-    "mpnn_grad_sumsq": [_I, _P, _P, _P, _P],
+    "mpnn_grad_sumsq": [_I, _P, _P, _P, _P, _I, _P],
     "mpnn_grad_scale": [_I, _P, _P, _P, _F, _P],
     "mpnn_adamw_step": [_I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _F, _P],
     "mpnn_linear_rows": [_P, _I, _I, _P, _P, ctypes.c_longlong, _P, _P],

@@ -74,7 +74,8 @@ __device__ __forceinline__ void zero_tile(f32x4 (&y)[MPNN_NT][KT]) {
 
 // LayerNorm backward over each column's 128 features, in registers.
 //   in : x = z (pre-LayerNorm input), d = dy;  out: d = dz, x = xhat (scratch)
-//   the weight / bias gradients sum_edges dy*xhat, sum_edges dy are added to lnacc[0:128], lnacc[128:256] (LDS)
+//   the weight / bias gradients sum_edges dy*xhat, sum_edges dy are added to lnacc[0:128], lnacc[128:256] (LDS):
+//   lnacc is THIS WAVE's accumulator (one writer lane per word, plain adds in the wave's own residue order - no atomics)
 template <int KT>
 __device__ __forceinline__ void tile_layernorm_bwd(f32x4 (&x)[MPNN_NT][KT], f32x4 (&d)[MPNN_NT][KT],
                                                    const float* __restrict__ ln_w, float* lnacc, int lane) {
@@ -112,8 +113,8 @@ __device__ __forceinline__ void tile_layernorm_bwd(f32x4 (&x)[MPNN_NT][KT], f32x
       for (int r = 0; r < 4; ++r) {
         const float vg = column_sum(sg[r]), vb = column_sum(sb[r]);
         if (col == 0) {
-          atomicAdd(&lnacc[16 * t + 4 * g + r], vg);
-          atomicAdd(&lnacc[MPNN_H + 16 * t + 4 * g + r], vb);
+          lnacc[16 * t + 4 * g + r] += vg;
+          lnacc[MPNN_H + 16 * t + 4 * g + r] += vb;
         }
       }
       FENCE();

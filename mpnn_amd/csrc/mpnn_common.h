@@ -499,6 +499,37 @@ __device__ __forceinline__ void load_feature_row(const float* __restrict__ row, 
 
 }  // namespace
 
+// Sums that cross workgroups (weight / bias / LayerNorm-parameter gradients, the loss, gradient norms) never meet by
+// floating-point atomics: every workgroup stores its partial to caller scratch and this kernel adds them in a fixed
+// tree - 16 slices of the partials per element (w = slice, slice + 16, ...), the slices met in LDS in slice order -
+// so that every run returns the same bits (run twice, bit-compare).
+//   out[e] (+)= sum_w part[w * stride + e],  e < n
+namespace {
+__global__ void __launch_bounds__(256)
+k_partials_reduce(const float* __restrict__ part, int nparts, long long stride, int n, float* __restrict__ out,
+                  int accumulate) {
+  __shared__ float sl[16][17];
+  const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
+  float s = 0.f;
+  if (e < n)
+    for (int w = slice; w < nparts; w += 16) s += part[(size_t)w * stride + e];
+  sl[slice][el] = s;
+  __syncthreads();
+  if (slice == 0 && e < n) {
+    float t = sl[0][el];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sl[k][el];
+    out[e] = accumulate ? out[e] + t : t;
+  }
+}
+}  // namespace
+
+static inline void launch_partials_reduce(const float* part, int nparts, long long stride, int n, float* out,
+                                          int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(k_partials_reduce, dim3((n + 15) / 16), dim3(256), 0, st, part, nparts, stride, n, out, accumulate);
+}
+
 // host-side error plumbing shared by the launchers
 extern "C" void mpnn_set_error(const char* msg);
 

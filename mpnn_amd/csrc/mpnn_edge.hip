@@ -899,15 +899,14 @@ k_message_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, in
     for (int t = 0; t < MPNN_NT; ++t) y[t][0] = *reinterpret_cast<const f32x4*>(b2 + 16 * t + 4 * g);
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) split_kstep<1, NKK, 0, MPNN_NT>(W2s, kk, lane, hb[kk], y);
-    float* gout = gsum + (size_t)node * MPNN_H + 4 * g;
+    // the tile's column sums go to its own row gsum[node][c] (plain stores; the node kernel adds a residue's tiles in
+    // tile order: no atomics, no re-zeroing, the same bits on every run)
+    float* gout = gsum + ((size_t)node * 4 + c) * MPNN_H + 4 * g;
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
       f32x4 sm = gelu4(y[t][0]) * w;
       sm = column_sum4(sm);
-      if (col == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(gout + 16 * t + r, sm[r]);
-      }
+      if (col == 0) *reinterpret_cast<f32x4*>(gout + 16 * t) = sm;
     }
   }
 }
@@ -953,7 +952,7 @@ __device__ __forceinline__ void lds_fill_commit(const LdsFill& f, h8* dst) {
 // what a wave knows about its message item before any layer runs: indices, scale / weight, where its hE tile is
 struct LevelItem {
   bool has, before;
-  int nl, node;
+  int nl, node, c;  // local residue, its id, column tile of this item
   float sc, w;
   size_t rowA, rowB;  // row numbers of the gathered neighbour row in the A buffer / in the encoder rows
   const f32x4* x;     // this lane's slice of the item's hE tile (feature tile t at x[t * xs])
@@ -970,6 +969,7 @@ level_item_setup(LevelItem& it, const f32x4* __restrict__ hE, const int* __restr
   it.has = wave < nlive * KT;
   const int item = it.has ? wave : 0;
   const int c = item % KT;
+  it.c = c;
   it.nl = item / KT;
   it.node = node_list[tile * lvn + it.nl];
   const int sh = it.node % enc_mod, b = it.node / L;
@@ -1000,7 +1000,8 @@ level_rows_load(const LevelItem& it, const float* Abuf, int lda, int offA, const
   }
 }
 
-// message MLP of the item (weights in LDS), neighbour sum into gsl[nl] by LDS atomics
+// message MLP of the item (weights in LDS); the item's column sums go to its own row gsl[LV_NODES c + nl] (plain
+// stores: level_node adds a residue's column tiles in tile order - no atomics, the same bits on every run)
 __device__ __forceinline__ void
 level_message(const LevelItem& it, const h8* W1s, const h8* W2s, const float* __restrict__ b2, const float* Pbuf,
               int ldp, int offP, const f32x4 (&xt)[MPNN_NT], f32x4 (&h1)[MPNN_NT][1], float (*gsl)[MPNN_H]) {
@@ -1032,7 +1033,7 @@ level_message(const LevelItem& it, const h8* W1s, const h8* W2s, const float* __
     sm = column_sum4(sm);
     if (col == 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&gsl[it.nl][16 * t + 4 * g + r], sm[r]);
+      for (int r = 0; r < 4; ++r) gsl[LV_NODES * it.c + it.nl][16 * t + 4 * g + r] = sm[r];
     }
   }
 }
@@ -1081,7 +1082,11 @@ level_node(h8* lds, float (*gsl)[MPNN_H], const W3Frags& w3, const int* __restri
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
       h[t][0] = *reinterpret_cast<const f32x4*>(hV_in + (size_t)nd * MPNN_H + 16 * t + 4 * g);
-      gs[t][0] = *reinterpret_cast<const f32x4*>(&gsl[col][16 * t + 4 * g]);
+      gs[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (col < LV_NODES)  // column tiles 0, 1, 2 of the residue, in that order (rows of absent tiles are zero)
+        gs[t][0] = (*reinterpret_cast<const f32x4*>(&gsl[col][16 * t + 4 * g]) +
+                    *reinterpret_cast<const f32x4*>(&gsl[LV_NODES + col][16 * t + 4 * g])) +
+                   *reinterpret_cast<const f32x4*>(&gsl[2 * LV_NODES + col][16 * t + 4 * g]);
     }
     tile_to_bfrag<MPNN_NT, 1, false>(gs, xb);
     f32x4 d1 = *reinterpret_cast<const f32x4*>(b3 + 16 * wave + 4 * g) * cnt_const;

@@ -167,8 +167,9 @@ k_message_bwd(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, con
 
 // ---------------------------------------------------------------------------
 // encoder edge-update backward.  dE may alias dy (each wave reads its residue's dy before writing).
-// LayerNorm parameter gradients are reduced per workgroup in LDS, then added to dln[0:128] (weight) and
-// dln[128:256] (bias) with one atomic per entry and workgroup.
+// LayerNorm parameter gradients: every wave sums its own residues in LDS, the workgroup adds its waves in wave order
+// and stores the partial to ln_part[blockIdx.x][256]; the launcher's k_partials_reduce adds the workgroups in a
+// fixed order into dln[0:128] (weight) and dln[128:256] (bias).  No floating-point atomics: bit-reproducible.
 // ---------------------------------------------------------------------------
 // W11b^T stream of the edge-update backward: fragments in flight ahead of their MFMAs, and the pointer's address space
 #ifndef MPNN_BWD_W1_RING
@@ -188,16 +189,17 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
                   const f32x4* __restrict__ a1, const float* __restrict__ ln_w, const h8* __restrict__ W13T,
                   const h8* __restrict__ W12T, const h8* __restrict__ W11bT, int N, f32x4* __restrict__ dz_out,
                   f32x4* __restrict__ da2_out, float* __restrict__ da1_nat, float* __restrict__ dP, f32x4* dE,
-                  float* __restrict__ dln, unsigned* __restrict__ amax, unsigned drop_thresh, unsigned drop_seed,
+                  float* __restrict__ ln_part, unsigned* __restrict__ amax, unsigned drop_thresh, unsigned drop_seed,
                   float inv_keep) {
   __shared__ h8 lds[2 * WSPLIT];
-  __shared__ float lnacc[2 * MPNN_H];
+  __shared__ float lnacc_w[MPNN_BWD_WAVES][2 * MPNN_H];
   __shared__ unsigned amax_l[3];
   if (threadIdx.x < 3) amax_l[threadIdx.x] = 0u;
   lds_fill(lds, W13T, WSPLIT);
   lds_fill(lds + WSPLIT, W12T, WSPLIT);
-  if (threadIdx.x < 2 * MPNN_H) lnacc[threadIdx.x] = 0.f;
+  for (int i = threadIdx.x; i < MPNN_BWD_WAVES * 2 * MPNN_H; i += blockDim.x) (&lnacc_w[0][0])[i] = 0.f;
   __syncthreads();
+  float* lnacc = lnacc_w[threadIdx.x >> 6];
   const h8* W3s = lds;
   const h8* W2s = lds + WSPLIT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -306,8 +308,13 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
 #endif
   }
   __syncthreads();
-  if (threadIdx.x < 2 * MPNN_H) unsafeAtomicAdd(dln + threadIdx.x, lnacc[threadIdx.x]);
-  if (threadIdx.x < 3) atomicMax(amax + threadIdx.x, amax_l[threadIdx.x]);
+  if (threadIdx.x < 2 * MPNN_H) {
+    float t = lnacc_w[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < MPNN_BWD_WAVES; ++w) t += lnacc_w[w][threadIdx.x];
+    ln_part[(size_t)blockIdx.x * 2 * MPNN_H + threadIdx.x] = t;
+  }
+  if (threadIdx.x < 3) atomicMax(amax + threadIdx.x, amax_l[threadIdx.x]);  // a maximum: order-independent
 }
 
 // ---------------------------------------------------------------------------
@@ -319,15 +326,16 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
 template <int KT>
 __global__ void __launch_bounds__(MPNN_BWD_WAVES * 64)
 k_features_bwd(const f32x4* __restrict__ dy, const f32x4* __restrict__ E0, const float* __restrict__ ln_w,
-               const h8* __restrict__ WeT, int N, f32x4* __restrict__ dE0, float* __restrict__ dln,
+               const h8* __restrict__ WeT, int N, f32x4* __restrict__ dE0, float* __restrict__ ln_part,
                unsigned* __restrict__ amax) {
   __shared__ h8 lds[WSPLIT];
-  __shared__ float lnacc[2 * MPNN_H];
+  __shared__ float lnacc_w[MPNN_BWD_WAVES][2 * MPNN_H];
   __shared__ unsigned amax_l[2];
   lds_fill(lds, WeT, WSPLIT);
-  if (threadIdx.x < 2 * MPNN_H) lnacc[threadIdx.x] = 0.f;
+  for (int i = threadIdx.x; i < MPNN_BWD_WAVES * 2 * MPNN_H; i += blockDim.x) (&lnacc_w[0][0])[i] = 0.f;
   if (threadIdx.x < 2) amax_l[threadIdx.x] = 0u;
   __syncthreads();
+  float* lnacc = lnacc_w[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int stride = gridDim.x * MPNN_BWD_WAVES;
   for (int node = blockIdx.x * MPNN_BWD_WAVES + wave; node < N; node += stride) {
@@ -358,7 +366,12 @@ k_features_bwd(const f32x4* __restrict__ dy, const f32x4* __restrict__ E0, const
       for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(d[t][c], &dE0[off + (t * KT + c) * 64]);
   }
   __syncthreads();
-  if (threadIdx.x < 2 * MPNN_H) unsafeAtomicAdd(dln + threadIdx.x, lnacc[threadIdx.x]);
+  if (threadIdx.x < 2 * MPNN_H) {
+    float t = lnacc_w[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < MPNN_BWD_WAVES; ++w) t += lnacc_w[w][threadIdx.x];
+    ln_part[(size_t)blockIdx.x * 2 * MPNN_H + threadIdx.x] = t;
+  }
   if (threadIdx.x < 2) atomicMax(amax + threadIdx.x, amax_l[threadIdx.x]);
 }
 
@@ -615,43 +628,54 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
     }
 }
 
-// dW[i] += sum_w part[w][i]  (slice blockIdx.y of the partials; slices meet with one atomic per element)
+// dW[i] += sum_w part[w][i]: 16 slices of the workgroup partials per element, met in LDS in slice order (no atomics:
+// the same bits on every run)
 __global__ void __launch_bounds__(256)
 k_wgrad_reduce(const float* __restrict__ part, int nparts, float* __restrict__ dW, float* __restrict__ db) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= WG_PART) return;
+  __shared__ float sl[16][17];
+  const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + el;
   float s = 0.f;
-  for (int w = blockIdx.y; w < nparts; w += gridDim.y) s += part[(size_t)w * WG_PART + i];
-  if (i < MPNN_H * MPNN_H)
-    unsafeAtomicAdd(dW + i, s);
-  else if (db)
-    unsafeAtomicAdd(db + (i - MPNN_H * MPNN_H), s);
+  if (i < WG_PART)
+    for (int w = slice; w < nparts; w += 16) s += part[(size_t)w * WG_PART + i];
+  sl[slice][el] = s;
+  __syncthreads();
+  if (slice == 0 && i < WG_PART) {
+    float t = sl[0][el];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sl[k][el];
+    if (i < MPNN_H * MPNN_H)
+      dW[i] += t;
+    else if (db)
+      db[i - MPNN_H * MPNN_H] += t;
+  }
 }
 
 // ---------------------------------------------------------------------------
-// out[j] += sum of the rows listed for node j (inverse neighbour list: rows that gathered node j in forward).
+// out[j] = sum of the rows listed for node j (inverse neighbour list: rows that gathered node j in forward).
 // sel (optional, per list entry): 0 -> outA, 1 -> outB  (decoder: row came from the A or the encoder block)
 // In-degrees are very uneven (hub residues are gathered by hundreds of neighbours), so the unit of work is a CHUNK
-// of at most 32 list entries: wave w finds its (node, chunk) by binary search in chunk_ptr (prefix sum of
-// ceil(degree / 32)), reads its rows as coalesced 512-byte lines (8 in flight) and adds its partial sum to the
-// zero-initialised outputs with fp32 atomics.
+// of at most 64 list entries: wave w looks its node up in chunk_node (written with the lists), reads its rows as
+// coalesced 512-byte lines (8 in flight) in list order and
+//   - a node with ONE chunk (in-degree <= 64: nearly all at K = 48) gets its sums by plain stores;
+//   - a chunk of a node with several writes its partial sums to part[w], and k_gather_finish adds a node's partials
+//     in chunk order.
+// Every output row is written exactly once, in a fixed summation order: no atomics, no zero fill, the same bits on
+// every run (the round-2 form met 32-entry partials by fp32 atomics).
 // ---------------------------------------------------------------------------
-constexpr int GATHER_CHUNK = 32;
+constexpr int GATHER_CHUNK = 64;
 
 __global__ void __launch_bounds__(256)
 k_gather_rows(const float* __restrict__ rows, const int* __restrict__ inv_ptr, const int* __restrict__ inv_row,
-              const unsigned char* __restrict__ sel, const int* __restrict__ chunk_ptr, int N, int n_waves,
-              float* __restrict__ outA, float* __restrict__ outB) {
+              const unsigned char* __restrict__ sel, const int* __restrict__ chunk_ptr,
+              const int* __restrict__ chunk_node, int N, int n_waves, float* __restrict__ outA,
+              float* __restrict__ outB, float* __restrict__ part) {
   const int lane = threadIdx.x & 63;
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= n_waves || w >= chunk_ptr[N]) return;
-  int lo = 0, hi = N;  // largest j with chunk_ptr[j] <= w
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (chunk_ptr[mid] <= w) lo = mid; else hi = mid;
-  }
-  const int j = lo;
-  const int m0 = inv_ptr[j] + (w - chunk_ptr[j]) * GATHER_CHUNK;
+  const int j = chunk_node[w];
+  const int c0 = chunk_ptr[j], nch = chunk_ptr[j + 1] - c0;
+  const int m0 = inv_ptr[j] + (w - c0) * GATHER_CHUNK;
   const int m1 = min(inv_ptr[j + 1], m0 + GATHER_CHUNK);
   // half a wave per row (32 lanes x 16 B = one 512-byte row), two rows per load instruction, 8 instructions in flight
   // (16 in flight - a whole chunk at once - was measured three times slower)
@@ -681,15 +705,31 @@ k_gather_rows(const float* __restrict__ rows, const int* __restrict__ inv_ptr, c
     sb[r] += __shfl_xor(sb[r], 32);
   }
   if (half == 0) {
-    float* oa = outA + (size_t)j * MPNN_H + 4 * q;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) unsafeAtomicAdd(oa + r, sa[r]);
-    if (outB) {
-      float* ob = outB + (size_t)j * MPNN_H + 4 * q;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) unsafeAtomicAdd(ob + r, sb[r]);
+    if (nch == 1) {
+      *(reinterpret_cast<f32x4*>(outA + (size_t)j * MPNN_H) + q) = sa;
+      if (outB) *(reinterpret_cast<f32x4*>(outB + (size_t)j * MPNN_H) + q) = sb;
+    } else {
+      *(reinterpret_cast<f32x4*>(part + (size_t)w * 2 * MPNN_H) + q) = sa;
+      if (outB) *(reinterpret_cast<f32x4*>(part + (size_t)w * 2 * MPNN_H + MPNN_H) + q) = sb;
     }
   }
+}
+
+// nodes with several chunks: out[j] = part[c0] + part[c0 + 1] + ... in chunk order (half a wave per node)
+__global__ void __launch_bounds__(256)
+k_gather_finish(const int* __restrict__ chunk_ptr, int N, const float* __restrict__ part, float* __restrict__ outA,
+                float* __restrict__ outB) {
+  const int j = blockIdx.x * 8 + (threadIdx.x >> 5), q = threadIdx.x & 31;
+  if (j >= N) return;
+  const int c0 = chunk_ptr[j], c1 = chunk_ptr[j + 1];
+  if (c1 - c0 <= 1) return;
+  f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sb = sa;
+  for (int c = c0; c < c1; ++c) {
+    sa += *(reinterpret_cast<const f32x4*>(part + (size_t)c * 2 * MPNN_H) + q);
+    if (outB) sb += *(reinterpret_cast<const f32x4*>(part + (size_t)c * 2 * MPNN_H + MPNN_H) + q);
+  }
+  *(reinterpret_cast<f32x4*>(outA + (size_t)j * MPNN_H) + q) = sa;
+  if (outB) *(reinterpret_cast<f32x4*>(outB + (size_t)j * MPNN_H) + q) = sb;
 }
 
 // ===========================================================================
@@ -726,22 +766,26 @@ extern "C" int mpnn_enc_edge_update_bwd(const float* dy_frag, const float* z_fra
                                         const float* a1_frag, const float* ln_w, const float* W13T_packed,
                                         const float* W12T_packed, const float* W11bT_packed, int B, int L, int K,
                                         float* dz_frag, float* da2_frag, float* da1_rows, float* dP, float* dE_frag,
-                                        float* dln, float* amax3, float p_drop, uint32_t drop_seed, void* stream) {
+                                        float* dln, float* amax3, float p_drop, uint32_t drop_seed, float* workspace,
+                                        int workspace_floats, void* stream) {
   MPNN_CHECK_ARG(dy_frag && z_frag && a2_frag && a1_frag && ln_w && W13T_packed && W12T_packed && W11bT_packed &&
-                     dz_frag && da2_frag && da1_rows && dP && dE_frag && dln && amax3,
+                     dz_frag && da2_frag && da1_rows && dP && dE_frag && dln && amax3 && workspace,
                  "mpnn_enc_edge_update_bwd: null pointer");
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64, "mpnn_enc_edge_update_bwd: bad sizes (K <= 64)");
   MPNN_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mpnn_enc_edge_update_bwd: dropout probability must be in [0, 1)");
   const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
   const int N = B * L, KT = (K + 15) / 16;
   dim3 grid(edge_grid(N, MPNN_BWD_WAVES)), block(MPNN_BWD_WAVES * 64);
+  MPNN_CHECK_ARG(workspace_floats >= (int)grid.x * 2 * MPNN_H,
+                 "mpnn_enc_edge_update_bwd: workspace too small (256 floats per workgroup, at most one workgroup per CU)");
   KT_DISPATCH(KT,
               hipLaunchKernelGGL((k_edge_update_bwd<kKT>), grid, block, 0, (hipStream_t)stream,
                                  (const f32x4*)dy_frag, (const f32x4*)z_frag, (const f32x4*)a2_frag,
                                  (const f32x4*)a1_frag, ln_w, (const h8*)W13T_packed, (const h8*)W12T_packed,
                                  (const h8*)W11bT_packed, N, (f32x4*)dz_frag, (f32x4*)da2_frag, da1_rows, dP,
-                                 (f32x4*)dE_frag, dln, (unsigned*)amax3, thresh, (unsigned)drop_seed,
+                                 (f32x4*)dE_frag, workspace, (unsigned*)amax3, thresh, (unsigned)drop_seed,
                                  1.0f / (1.0f - p_drop)));
+  launch_partials_reduce(workspace, (int)grid.x, 2 * MPNN_H, 2 * MPNN_H, dln, 1, (hipStream_t)stream);
   MPNN_LAUNCH_CHECK();
 }
 
@@ -777,8 +821,7 @@ extern "C" int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax
     if (b_gelu) MPNN_WGRAD_LAUNCH(false, true); else MPNN_WGRAD_LAUNCH(false, false);
   }
 #undef MPNN_WGRAD_LAUNCH
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((WG_PART + 255) / 256, nwg < 16 ? nwg : 16), dim3(256), 0, st, workspace, nwg, dW,
-                     dbias);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((WG_PART + 15) / 16), dim3(256), 0, st, workspace, nwg, dW, dbias);
   MPNN_LAUNCH_CHECK();
 }
 
@@ -797,7 +840,8 @@ k_inv_mark(const int* __restrict__ E, long long n_edges, int L, int K, int Kp, u
   const int p = (int)(e / K), k = (int)(e - (long long)p * K);
   const int b = p / L;
   const int j = E[(size_t)p * Kp + k];  // local to the protein
-  slot[((size_t)b * L + j) * L + (p - b * L)] = (unsigned char)k;
+  // an index outside the protein is dropped here and shows as a short list (status word of mpnn_inverse_lists)
+  if ((unsigned)j < (unsigned)L) slot[((size_t)b * L + j) * L + (p - b * L)] = (unsigned char)k;
 }
 
 // FILL = false: deg[n] -> inv_ptr[n + 1];  FILL = true: the list of node n -> inv_row[inv_ptr[n] ...]
@@ -822,10 +866,14 @@ k_inv_rows(const unsigned char* __restrict__ slot, int N, int L, int Kp, int* __
   if (!FILL && lane == 0) inv_ptr[n + 1] = base;
 }
 
+// chunks of a node's list (mpnn_gather_rows): at least one, so that every node's output row gets written
+__device__ __forceinline__ int gather_chunks(int deg) { return deg <= GATHER_CHUNK ? 1 : (deg + GATHER_CHUNK - 1) / GATHER_CHUNK; }
+
 // one workgroup: inv_ptr[n + 1] holds deg[n] on entry and sum_{i <= n} deg[i] on exit (inv_ptr[0] = 0);
-// chunk_ptr likewise for ceil(deg / 32)
+// chunk_ptr likewise for the chunk counts; status (optional) = 1 when the lists do not hold n_edges entries (an index
+// out of range, or one neighbour listed twice by a residue: the slot map keeps one edge per (target, centre))
 __global__ void __launch_bounds__(1024)
-k_inv_scan(int N, int* __restrict__ inv_ptr, int* __restrict__ chunk_ptr) {
+k_inv_scan(int N, int* __restrict__ inv_ptr, int* __restrict__ chunk_ptr, long long n_edges, int* __restrict__ status) {
   __shared__ int sd[1024], sc[1024];
   const int t = threadIdx.x;
   const int per = (N + 1023) / 1024;
@@ -834,7 +882,7 @@ k_inv_scan(int N, int* __restrict__ inv_ptr, int* __restrict__ chunk_ptr) {
   for (int n = n0; n < n1; ++n) {
     const int deg = inv_ptr[n + 1];
     d += deg;
-    c += (deg + GATHER_CHUNK - 1) / GATHER_CHUNK;
+    c += gather_chunks(deg);
   }
   sd[t] = d;
   sc[t] = c;
@@ -851,10 +899,19 @@ k_inv_scan(int N, int* __restrict__ inv_ptr, int* __restrict__ chunk_ptr) {
   for (int n = n0; n < n1; ++n) {
     const int deg = inv_ptr[n + 1];
     rd += deg;
-    rc += (deg + GATHER_CHUNK - 1) / GATHER_CHUNK;
+    rc += gather_chunks(deg);
     inv_ptr[n + 1] = rd;
     chunk_ptr[n + 1] = rc;
   }
+  if (status && t == 1023) status[0] = (long long)sd[1023] != n_edges ? 1 : 0;
+}
+
+// chunk_node[c] = the node chunk c belongs to
+__global__ void __launch_bounds__(256)
+k_inv_chunk_nodes(const int* __restrict__ chunk_ptr, int N, int* __restrict__ chunk_node) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  for (int c = chunk_ptr[n]; c < chunk_ptr[n + 1]; ++c) chunk_node[c] = n;
 }
 
 // sel[m] = 1 where the edge's centre does not come after its target in the decoding order (the decoder read the
@@ -870,18 +927,22 @@ k_inv_sel(const int* __restrict__ rank, const int* __restrict__ inv_ptr, const i
 }
 
 extern "C" int mpnn_gather_rows(const float* rows, const int32_t* inv_ptr, const int32_t* inv_row,
-                                const unsigned char* sel, const int32_t* chunk_ptr, int n_nodes, int max_chunks,
-                                float* outA, float* outB, void* stream) {
-  MPNN_CHECK_ARG(rows && inv_ptr && inv_row && chunk_ptr && outA, "mpnn_gather_rows: null pointer");
+                                const unsigned char* sel, const int32_t* chunk_ptr, const int32_t* chunk_node,
+                                int n_nodes, int max_chunks, float* outA, float* outB, float* partials, void* stream) {
+  MPNN_CHECK_ARG(rows && inv_ptr && inv_row && chunk_ptr && chunk_node && outA && partials,
+                 "mpnn_gather_rows: null pointer");
   MPNN_CHECK_ARG(n_nodes > 0 && max_chunks > 0 && (!sel || outB), "mpnn_gather_rows: a selector needs the second output");
   hipLaunchKernelGGL(k_gather_rows, dim3((max_chunks + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, inv_ptr, inv_row,
-                     sel, chunk_ptr, n_nodes, max_chunks, outA, outB);
+                     sel, chunk_ptr, chunk_node, n_nodes, max_chunks, outA, outB, partials);
+  hipLaunchKernelGGL(k_gather_finish, dim3((n_nodes + 7) / 8), dim3(256), 0, (hipStream_t)stream, chunk_ptr, n_nodes,
+                     partials, outA, outB);
   MPNN_LAUNCH_CHECK();
 }
 
 extern "C" int mpnn_inverse_lists(const int32_t* E_idx32, int B, int L, int K, unsigned char* slot_map, int32_t* inv_ptr,
-                                  int32_t* chunk_ptr, int32_t* inv_row, void* stream) {
-  MPNN_CHECK_ARG(E_idx32 && slot_map && inv_ptr && chunk_ptr && inv_row, "mpnn_inverse_lists: null pointer");
+                                  int32_t* chunk_ptr, int32_t* chunk_node, int32_t* inv_row, int32_t* status,
+                                  void* stream) {
+  MPNN_CHECK_ARG(E_idx32 && slot_map && inv_ptr && chunk_ptr && chunk_node && inv_row, "mpnn_inverse_lists: null pointer");
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && K <= L, "mpnn_inverse_lists: bad sizes (1 <= K <= min(64, L))");
   MPNN_CHECK_ARG((long long)B * L * K < (1ll << 31) && (long long)B * L < (1ll << 31) / 64,
                  "mpnn_inverse_lists: more than 2^31 edges");
@@ -895,7 +956,8 @@ extern "C" int mpnn_inverse_lists(const int32_t* E_idx32, int B, int L, int K, u
   hipLaunchKernelGGL(k_inv_mark, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, st, E_idx32, n_edges, L, K, Kp,
                      slot_map);
   hipLaunchKernelGGL((k_inv_rows<false>), dim3((N + 3) / 4), dim3(256), 0, st, slot_map, N, L, Kp, inv_ptr, inv_row);
-  hipLaunchKernelGGL(k_inv_scan, dim3(1), dim3(1024), 0, st, N, inv_ptr, chunk_ptr);
+  hipLaunchKernelGGL(k_inv_scan, dim3(1), dim3(1024), 0, st, N, inv_ptr, chunk_ptr, n_edges, status);
+  hipLaunchKernelGGL(k_inv_chunk_nodes, dim3((N + 255) / 256), dim3(256), 0, st, chunk_ptr, N, chunk_node);
   hipLaunchKernelGGL((k_inv_rows<true>), dim3((N + 3) / 4), dim3(256), 0, st, slot_map, N, L, Kp, inv_ptr, inv_row);
   MPNN_LAUNCH_CHECK();
 }
@@ -911,15 +973,18 @@ extern "C" int mpnn_inverse_sel(const int32_t* rank, const int32_t* inv_ptr, con
 
 extern "C" int mpnn_edge_features_bwd(const float* dhE_frag, const float* E0_frag, const float* ln_w,
                                       const float* WeT_packed, int B, int L, int K, float* dE0_frag, float* dln,
-                                      float* amax2, void* stream) {
-  MPNN_CHECK_ARG(dhE_frag && E0_frag && ln_w && WeT_packed && dE0_frag && dln && amax2,
+                                      float* amax2, float* workspace, int workspace_floats, void* stream) {
+  MPNN_CHECK_ARG(dhE_frag && E0_frag && ln_w && WeT_packed && dE0_frag && dln && amax2 && workspace,
                  "mpnn_edge_features_bwd: null pointer");
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64, "mpnn_edge_features_bwd: bad sizes (K <= 64)");
   const int N = B * L, KT = (K + 15) / 16;
   dim3 grid(edge_grid(N, MPNN_BWD_WAVES)), block(MPNN_BWD_WAVES * 64);
+  MPNN_CHECK_ARG(workspace_floats >= (int)grid.x * 2 * MPNN_H,
+                 "mpnn_edge_features_bwd: workspace too small (256 floats per workgroup, at most one workgroup per CU)");
   KT_DISPATCH(KT,
               hipLaunchKernelGGL((k_features_bwd<kKT>), grid, block, 0, (hipStream_t)stream,
                                  (const f32x4*)dhE_frag, (const f32x4*)E0_frag, ln_w, (const h8*)WeT_packed, N,
-                                 (f32x4*)dE0_frag, dln, (unsigned*)amax2));
+                                 (f32x4*)dE0_frag, workspace, (unsigned*)amax2));
+  launch_partials_reduce(workspace, (int)grid.x, 2 * MPNN_H, 2 * MPNN_H, dln, 1, (hipStream_t)stream);
   MPNN_LAUNCH_CHECK();
 }

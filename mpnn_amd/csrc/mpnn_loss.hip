@@ -13,12 +13,12 @@ namespace {
 
 constexpr int HB_NODES = 64;    // nodes per workgroup
 constexpr int HB_MAXL = 32;     // letters (padded)
+constexpr int HB_PART = HB_MAXL * MPNN_H + HB_MAXL;  // floats of one workgroup's partial (dW | db)
 
 // d_logits = d_logp - softmax * sum(d_logp);  d_hV = d_logits W;  dW += d_logits^T hV;  db += sum_n d_logits
 __global__ void __launch_bounds__(256)
 k_head_bwd(const float* __restrict__ d_logp, const float* __restrict__ logp, const float* __restrict__ hV,
-           const float* __restrict__ W, int N, int n_letters, float* __restrict__ d_hV, float* __restrict__ dW,
-           float* __restrict__ db) {
+           const float* __restrict__ W, int N, int n_letters, float* __restrict__ d_hV, float* __restrict__ part) {
   __shared__ float dl[HB_NODES][HB_MAXL + 1];
   __shared__ float Wl[HB_MAXL][MPNN_H];
   __shared__ float hv[HB_NODES][MPNN_H + 4];
@@ -81,16 +81,15 @@ k_head_bwd(const float* __restrict__ d_logp, const float* __restrict__ logp, con
 #pragma unroll
       for (int u = 0; u < HB_MAXL / 2; ++u) acc[u] = fmaf(dl[n][a0 + 2 * u], h, acc[u]);
     }
+    // this workgroup's partial [HB_MAXL x 128 | HB_MAXL]: the launcher's k_partials_reduce adds them in a fixed order
+    float* P = part + (size_t)blockIdx.x * HB_PART;
 #pragma unroll
-    for (int u = 0; u < HB_MAXL / 2; ++u) {
-      const int a = a0 + 2 * u;
-      if (a < n_letters) unsafeAtomicAdd(dW + (size_t)a * MPNN_H + f, acc[u]);
-    }
+    for (int u = 0; u < HB_MAXL / 2; ++u) P[(size_t)(a0 + 2 * u) * MPNN_H + f] = acc[u];
   }
-  if (db && tid < n_letters) {
+  if (tid < HB_MAXL) {
     float s = 0.f;
     for (int n = 0; n < HB_NODES; ++n) s += dl[n][tid];
-    unsafeAtomicAdd(db + tid, s);
+    part[(size_t)blockIdx.x * HB_PART + HB_MAXL * MPNN_H + tid] = s;
   }
 }
 
@@ -98,7 +97,7 @@ k_head_bwd(const float* __restrict__ d_logp, const float* __restrict__ logp, con
 // d_logp[n,a] = -t[n,a] mask[n] scale   (the gradient of loss_sum)
 __global__ void __launch_bounds__(256)
 k_loss_smoothed(const float* __restrict__ logp, const long long* __restrict__ S, const float* __restrict__ mask, int N,
-                int n_letters, float weight, float scale, float* __restrict__ loss, float* __restrict__ loss_sum,
+                int n_letters, float weight, float scale, float* __restrict__ loss, float* __restrict__ loss_part,
                 float* __restrict__ d_logp) {
   __shared__ float part[4];
   const int n = blockIdx.x * 256 + threadIdx.x;
@@ -122,7 +121,23 @@ k_loss_smoothed(const float* __restrict__ logp, const long long* __restrict__ S,
   for (int o = 32; o >= 1; o >>= 1) contrib += __shfl_xor(contrib, o);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = contrib;
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(loss_sum, (part[0] + part[1]) + (part[2] + part[3]));
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// out[0] = sum of part[0 .. n) in a fixed tree (one workgroup: strided per-thread sums, then an LDS tree): the scalar
+// sums of the step (loss, squared gradient norm) without floating-point atomics
+__global__ void __launch_bounds__(1024)
+k_sum_ordered(const float* __restrict__ part, int n, float* __restrict__ out) {
+  __shared__ float sh[1024];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) s += part[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
 }
 
 // element-wise probes of the two device helpers every MLP on the path is built from (unit tests of the arithmetic):
@@ -165,13 +180,13 @@ struct MultiTensor {
 };
 constexpr int MT_CHUNK = 2048;  // elements per workgroup
 
-// sumsq[0] += sum of squares of every gradient element (fp32 partials, one atomic per workgroup)
+// ss_part[blockIdx.y * gridDim.x + blockIdx.x] = sum of squares of this workgroup's chunk of gradient elements
+// (0 past a tensor's end); k_sum_ordered adds the partials
 __global__ void __launch_bounds__(256)
-k_grad_sumsq(MultiTensor t, float* __restrict__ sumsq) {
+k_grad_sumsq(MultiTensor t, float* __restrict__ ss_part) {
   __shared__ float part[4];
   const int ti = blockIdx.y, n = t.numel[ti];
   const int i0 = blockIdx.x * MT_CHUNK;
-  if (i0 >= n) return;
   const float* __restrict__ g = t.g[ti];
   float s = 0.f;
   for (int i = i0 + threadIdx.x; i < min(n, i0 + MT_CHUNK); i += 256) s += g[i] * g[i];
@@ -179,7 +194,7 @@ k_grad_sumsq(MultiTensor t, float* __restrict__ sumsq) {
   for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(sumsq, (part[0] + part[1]) + (part[2] + part[3]));
+  if (threadIdx.x == 0) ss_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 // torch.nn.utils.clip_grad_norm_: g *= min(1, max_norm / (sqrt(sumsq) + 1e-6))
@@ -254,15 +269,35 @@ __global__ void k_range_flag(const float* __restrict__ x, long long n, float lim
 
 }  // namespace
 
-extern "C" int mpnn_grad_sumsq(int n, const float* const* grads, const int* numel, float* sumsq, void* stream) {
-  MPNN_CHECK_ARG(n > 0 && grads && numel && sumsq, "mpnn_grad_sumsq: bad arguments");
+static long long sumsq_partials(int n, const int* numel) {
+  long long total = 0;
+  for (int k0 = 0; k0 < n; k0 += MT_MAX) {
+    int mx = 0;
+    const int m = n - k0 < MT_MAX ? n - k0 : MT_MAX;
+    for (int j = 0; j < m; ++j) mx = numel[k0 + j] > mx ? numel[k0 + j] : mx;
+    total += (long long)((mx + MT_CHUNK - 1) / MT_CHUNK) * m;
+  }
+  return total;
+}
+
+extern "C" int mpnn_grad_sumsq(int n, const float* const* grads, const int* numel, float* sumsq, float* workspace,
+                               int workspace_floats, void* stream) {
+  MPNN_CHECK_ARG(n > 0 && grads && numel && sumsq && workspace, "mpnn_grad_sumsq: bad arguments");
   for (int j = 0; j < n; ++j) MPNN_CHECK_ARG(grads[j] && numel[j] > 0, "mpnn_grad_sumsq: null or empty tensor");
+  const long long need = sumsq_partials(n, numel);
+  MPNN_CHECK_ARG(need <= workspace_floats,
+                 "mpnn_grad_sumsq: workspace too small (one float per 2048 elements of the largest tensor of each group of "
+                 "48 tensors, times the tensors of the group)");
+  long long off = 0;
   for (int k0 = 0; k0 < n; k0 += MT_MAX) {
     MultiTensor t;
     int mx;
     fill_table(t, k0, n, nullptr, grads, nullptr, nullptr, numel, &mx);
-    hipLaunchKernelGGL(k_grad_sumsq, dim3((mx + MT_CHUNK - 1) / MT_CHUNK, t.n), dim3(256), 0, (hipStream_t)stream, t, sumsq);
+    const int gx = (mx + MT_CHUNK - 1) / MT_CHUNK;
+    hipLaunchKernelGGL(k_grad_sumsq, dim3(gx, t.n), dim3(256), 0, (hipStream_t)stream, t, workspace + off);
+    off += (long long)gx * t.n;
   }
+  hipLaunchKernelGGL(k_sum_ordered, dim3(1), dim3(1024), 0, (hipStream_t)stream, workspace, (int)need, sumsq);
   MPNN_LAUNCH_CHECK();
 }
 
@@ -315,20 +350,28 @@ extern "C" int mpnn_probe_elementwise(const float* x, int n, int mode, float* y,
 
 extern "C" int mpnn_logits_log_softmax_bwd(const float* d_log_probs, const float* log_probs, const float* hV,
                                            const float* W_out, int n_letters, int n_nodes, float* d_hV, float* dW,
-                                           float* db, void* stream) {
-  MPNN_CHECK_ARG(d_log_probs && log_probs && hV && W_out && d_hV && dW, "mpnn_logits_log_softmax_bwd: null pointer");
+                                           float* db, float* workspace, int workspace_floats, void* stream) {
+  MPNN_CHECK_ARG(d_log_probs && log_probs && hV && W_out && d_hV && dW && workspace, "mpnn_logits_log_softmax_bwd: null pointer");
   MPNN_CHECK_ARG(n_nodes > 0 && n_letters >= 1 && n_letters <= HB_MAXL, "mpnn_logits_log_softmax_bwd: bad sizes");
-  hipLaunchKernelGGL(k_head_bwd, dim3((n_nodes + HB_NODES - 1) / HB_NODES), dim3(256), 0, (hipStream_t)stream,
-                     d_log_probs, log_probs, hV, W_out, n_nodes, n_letters, d_hV, dW, db);
+  const int n_wg = (n_nodes + HB_NODES - 1) / HB_NODES;
+  MPNN_CHECK_ARG((long long)workspace_floats >= (long long)n_wg * HB_PART,
+                 "mpnn_logits_log_softmax_bwd: workspace too small (4128 floats per 64 nodes)");
+  hipLaunchKernelGGL(k_head_bwd, dim3(n_wg), dim3(256), 0, (hipStream_t)stream, d_log_probs, log_probs, hV, W_out, n_nodes,
+                     n_letters, d_hV, workspace);
+  launch_partials_reduce(workspace, n_wg, HB_PART, n_letters * MPNN_H, dW, 1, (hipStream_t)stream);
+  if (db) launch_partials_reduce(workspace + HB_MAXL * MPNN_H, n_wg, HB_PART, n_letters, db, 1, (hipStream_t)stream);
   MPNN_LAUNCH_CHECK();
 }
 
 extern "C" int mpnn_loss_smoothed(const float* log_probs, const int64_t* S, const float* mask, int n_nodes,
                                   int n_letters, float weight, float scale, float* loss, float* loss_sum,
-                                  float* d_log_probs, void* stream) {
-  MPNN_CHECK_ARG(log_probs && S && mask && loss && loss_sum, "mpnn_loss_smoothed: null pointer");
+                                  float* d_log_probs, float* workspace, int workspace_floats, void* stream) {
+  MPNN_CHECK_ARG(log_probs && S && mask && loss && loss_sum && workspace, "mpnn_loss_smoothed: null pointer");
   MPNN_CHECK_ARG(n_nodes > 0 && n_letters >= 1, "mpnn_loss_smoothed: bad sizes");
-  hipLaunchKernelGGL(k_loss_smoothed, dim3((n_nodes + 255) / 256), dim3(256), 0, (hipStream_t)stream, log_probs,
-                     (const long long*)S, mask, n_nodes, n_letters, weight, scale, loss, loss_sum, d_log_probs);
+  const int n_wg = (n_nodes + 255) / 256;
+  MPNN_CHECK_ARG(workspace_floats >= n_wg, "mpnn_loss_smoothed: workspace too small (one float per 256 nodes)");
+  hipLaunchKernelGGL(k_loss_smoothed, dim3(n_wg), dim3(256), 0, (hipStream_t)stream, log_probs, (const long long*)S, mask,
+                     n_nodes, n_letters, weight, scale, loss, workspace, d_log_probs);
+  hipLaunchKernelGGL(k_sum_ordered, dim3(1), dim3(1024), 0, (hipStream_t)stream, workspace, n_wg, loss_sum);
   MPNN_LAUNCH_CHECK();
 }

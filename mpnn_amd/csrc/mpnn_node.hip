@@ -220,13 +220,14 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
 // throughput, matters, so the 11 matrix stages of k_node_update are spread over the 4 waves of a 16-node workgroup:
 //   W3 by output-tile pairs, the FFN by hidden quarters (W_in_q and W_out_q per wave), the projections by halves;
 // partial results meet through a 32 KiB LDS exchange buffer, weights stream straight from L2.  Same maths as
-// k_node_update (cnt = cnt_const, no table add); reads AND RE-ZEROES its gsum rows (k_message_level accumulates).
+// k_node_update (cnt = cnt_const, no table add); gsum is [node][4][128]: the residue's column-tile sums as
+// k_message_level stores them, added here in tile order (n_tiles of them).
 // ---------------------------------------------------------------------------
 #ifndef MPNN_LEVEL_RING
 #define MPNN_LEVEL_RING 8  // weight fragments in flight per wave (L2 -> registers) in k_node_update_level
 #endif
 __global__ void __launch_bounds__(256)
-k_node_update_level(const float* __restrict__ hV_in, float* __restrict__ gsum, float cnt_const,
+k_node_update_level(const float* __restrict__ hV_in, const float* __restrict__ gsum, int n_tiles, float cnt_const,
                     const float* __restrict__ mask, const h8* __restrict__ W3, const float* __restrict__ b3,
                     const float* __restrict__ ln1w, const float* __restrict__ ln1b, const h8* __restrict__ Win,
                     const float* __restrict__ bin, const h8* __restrict__ Wout, const float* __restrict__ bout,
@@ -244,7 +245,9 @@ k_node_update_level(const float* __restrict__ hV_in, float* __restrict__ gsum, f
 #pragma unroll
   for (int t = 0; t < MPNN_NT; ++t) {
     h[t][0] = *reinterpret_cast<const f32x4*>(hV_in + (size_t)nd * MPNN_H + 16 * t + 4 * g);
-    gs[t][0] = *reinterpret_cast<const f32x4*>(gsum + (size_t)nd * MPNN_H + 16 * t + 4 * g);
+    gs[t][0] = *reinterpret_cast<const f32x4*>(gsum + (size_t)nd * 4 * MPNN_H + 16 * t + 4 * g);
+    for (int c = 1; c < n_tiles; ++c)
+      gs[t][0] += *reinterpret_cast<const f32x4*>(gsum + ((size_t)nd * 4 + c) * MPNN_H + 16 * t + 4 * g);
   }
   BFrag xb[NKK][1];
   tile_to_bfrag<MPNN_NT, 1, false>(gs, xb);
@@ -257,11 +260,6 @@ k_node_update_level(const float* __restrict__ hV_in, float* __restrict__ gsum, f
     ex[0][2 * wave + 1][lane] = d2[1][0];
   }
   __syncthreads();
-  if (wave == 0 && live) {
-#pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t)
-      *reinterpret_cast<f32x4*>(gsum + (size_t)nd * MPNN_H + 16 * t + 4 * g) = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
 #pragma unroll
   for (int t = 0; t < MPNN_NT; ++t) h[t][0] += ex[0][t][lane] * inv_scale;
   tile_layernorm<1>(h, ln1w, ln1b, lane);
@@ -467,7 +465,8 @@ extern "C" int MPNN_API(mpnn_linear_rows)(const float* x, int ldx, int in_f, con
   MPNN_LAUNCH_CHECK();
 }
 
-extern "C" int MPNN_API(mpnn_node_update_subset)(const float* hV_in, float* gsum, float cnt_const, const float* mask,
+extern "C" int MPNN_API(mpnn_node_update_subset)(const float* hV_in, const float* gsum, int n_tiles, float cnt_const,
+                                       const float* mask,
                                        const float* W3_packed, const float* b3, const float* ln1_w,
                                        const float* ln1_b, const float* Win_packed, const float* b_in,
                                        const float* Wout_packed, const float* b_out, const float* ln2_w,
@@ -475,11 +474,12 @@ extern "C" int MPNN_API(mpnn_node_update_subset)(const float* hV_in, float* gsum
                                        int nproj, const int32_t* node_list, int n_list, float* hV_out, float* PQ,
                                        void* stream) {
   MPNN_CHECK_ARG(hV_in && gsum && mask && W3_packed && b3 && ln1_w && ln1_b && Win_packed && b_in && Wout_packed &&
-                     b_out && ln2_w && ln2_b && hV_out && node_list && n_list > 0 && nproj >= 0,
-                 "mpnn_node_update_subset: bad arguments");
+                     b_out && ln2_w && ln2_b && hV_out && node_list && n_list > 0 && nproj >= 0 && n_tiles >= 1 &&
+                     n_tiles <= 4,
+                 "mpnn_node_update_subset: bad arguments (1 .. 4 column tiles)");
   MPNN_CHECK_ARG(nproj == 0 || (Wproj_packed && bproj && PQ), "mpnn_node_update_subset: projections need Wproj, bproj, PQ");
   hipLaunchKernelGGL(k_node_update_level, dim3(ceil_div(n_list, 16)), dim3(256), 0, (hipStream_t)stream, hV_in, gsum,
-                     cnt_const, mask, (const h8*)W3_packed, b3, ln1_w, ln1_b, (const h8*)Win_packed, b_in,
+                     n_tiles, cnt_const, mask, (const h8*)W3_packed, b3, ln1_w, ln1_b, (const h8*)Win_packed, b_in,
                      (const h8*)Wout_packed, b_out, ln2_w, ln2_b, 1.0f / scale, (const h8*)Wproj_packed, bproj, nproj,
                      node_list, n_list, hV_out, PQ);
   MPNN_LAUNCH_CHECK();

@@ -187,27 +187,35 @@ k_node_wgrad_split(WgradJobs jb, int N, int rows_per_wg, float* __restrict__ par
   }
 }
 
-// dW block (blockIdx.y, blockIdx.z) += sum over row chunks of the partial tiles; chunk slices meet by atomics
+// dW block blockIdx.y += sum over row chunks of the partial tiles: 4 slices of the chunks per element, met in LDS in
+// slice order (no atomics: the same bits on every run)
 __global__ void __launch_bounds__(256)
 k_node_wgrad_reduce(const float* __restrict__ part, int nx, WgradJobs jb) {
-  const int e = blockIdx.x * 256 + threadIdx.x;  // element of the 128x128 (+128 bias) partial
-  const int slice = blockIdx.y % 4, blk = blockIdx.y / 4;
+  __shared__ float sl[4][64];
+  const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;  // element of the 128x128 (+128 bias) partial
+  const int blk = blockIdx.y;
   const int job = find_job(jb, blk);
   const int local = blk - jb.blk0[job];
   const int by = local % jb.ny[job], bz = local / jb.ny[job];
   const int out_f = jb.out_f[job], in_f = jb.in_f[job], ldw = jb.ldw[job];
   float* __restrict__ dW = jb.dW[job];
   float* __restrict__ db = jb.db[job];
-  if (e >= NW_PART) return;
-  const float* P = part + (size_t)blk * nx * NW_PART + e;
   float s = 0.f;
-  for (int w = slice; w < nx; w += 4) s += P[(size_t)w * NW_PART];
+  if (e < NW_PART) {
+    const float* P = part + (size_t)blk * nx * NW_PART + e;
+    for (int w = slice; w < nx; w += 4) s += P[(size_t)w * NW_PART];
+  }
+  sl[slice][el] = s;
+  __syncthreads();
+  if (slice != 0 || e >= NW_PART) return;
+  s = ((sl[0][el] + sl[1][el]) + sl[2][el]) + sl[3][el];
   if (e < 128 * 128) {
     const int o = by * 128 + e / 128, i = bz * 128 + e % 128;
-    if (o < out_f && i < in_f) unsafeAtomicAdd(dW + (size_t)o * ldw + i, s);
+    if (o < out_f && i < in_f) dW[(size_t)o * ldw + i] += s;
   } else if (db && bz == 0) {
     const int o = by * 128 + (e - 128 * 128);
-    if (o < out_f) unsafeAtomicAdd(db + o, s);
+    if (o < out_f) db[o] += s;
   }
 }
 
@@ -370,8 +378,9 @@ k_node_update_train(const float* __restrict__ hV_in, const float* __restrict__ g
 //   da_q  = (W_out_q^T do) gelu'(a_q)                    dx1 = dx2pre + sum_q W_in_q^T da_q
 //   dx1pre = LN1'(dx1; x1pre) = d hV_in                  ddh = drop1'(dx1pre) / scale    dgsum = W3^T ddh
 // Written out for the weight gradients (mpnn_node_wgrad): x1, gelu(a), da, do, ddh.  LayerNorm parameter
-// gradients and db3 = sum_n cnt_n ddh_n are reduced per workgroup in LDS, then added to dvec[0:640]
-// (ln1.w, ln1.b, ln2.w, ln2.b, b3) with one atomic per entry and workgroup.
+// gradients and db3 = sum_n cnt_n ddh_n: every wave sums its own 16 nodes in LDS, the workgroup adds its waves in wave
+// order and stores vec_part[blockIdx.x][640]; the launcher's k_partials_reduce adds the workgroups in a fixed order
+// into dvec[0:640] (ln1.w, ln1.b, ln2.w, ln2.b, b3).  No floating-point atomics.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_node_update_bwd(const float* __restrict__ dY, const float* __restrict__ dPQ, const float* __restrict__ s_x1pre,
@@ -381,9 +390,12 @@ k_node_update_bwd(const float* __restrict__ dY, const float* __restrict__ dPQ, c
                   const h8* __restrict__ WprojT, int nproj, const h8* __restrict__ WoutT, const h8* __restrict__ WinT,
                   const h8* __restrict__ W3T, int N, float* __restrict__ d_hV_in, float* __restrict__ d_gsum,
                   float* __restrict__ o_x1, float* __restrict__ o_hid, float* __restrict__ o_da,
-                  float* __restrict__ o_do, float* __restrict__ o_ddh, float* __restrict__ dvec, DropCfg dc) {
+                  float* __restrict__ o_do, float* __restrict__ o_ddh, float* __restrict__ vec_part, DropCfg dc) {
   __shared__ h8 lds[2 * WSPLIT_N];
-  __shared__ float acc1[2 * MPNN_H], acc2[2 * MPNN_H], accb3[MPNN_H];
+  __shared__ float acc1_w[4][2 * MPNN_H], acc2_w[4][2 * MPNN_H], accb3_w[4][MPNN_H];
+  float* acc1 = acc1_w[threadIdx.x >> 6];
+  float* acc2 = acc2_w[threadIdx.x >> 6];
+  float* accb3 = accb3_w[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int g = lane >> 4, col = lane & 15;
@@ -407,10 +419,10 @@ k_node_update_bwd(const float* __restrict__ dY, const float* __restrict__ dPQ, c
     __syncthreads();
     ++k;
   };
-  for (int i = threadIdx.x; i < 2 * MPNN_H; i += 256) {
-    acc1[i] = 0.f;
-    acc2[i] = 0.f;
-    if (i < MPNN_H) accb3[i] = 0.f;
+  for (int i = threadIdx.x; i < 4 * 2 * MPNN_H; i += 256) {
+    (&acc1_w[0][0])[i] = 0.f;
+    (&acc2_w[0][0])[i] = 0.f;
+    if (i < 4 * MPNN_H) (&accb3_w[0][0])[i] = 0.f;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -495,7 +507,7 @@ k_node_update_bwd(const float* __restrict__ dY, const float* __restrict__ dPQ, c
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float v = column_sum(dd[r] * cn);
-      if (col == 0) atomicAdd(&accb3[16 * t + 4 * g + r], v);
+      if (col == 0) accb3[16 * t + 4 * g + r] += v;
     }
   }
   const float un = grad_to_bfrag<1>(tmp, bf, nullptr);
@@ -509,10 +521,11 @@ k_node_update_bwd(const float* __restrict__ dY, const float* __restrict__ dPQ, c
       *reinterpret_cast<f32x4*>(d_gsum + (size_t)node * MPNN_H + 16 * t + 4 * g) = x[t][0] * un;
   }
   __syncthreads();
+  float* vp = vec_part + (size_t)blockIdx.x * 5 * MPNN_H;
   for (int i = threadIdx.x; i < 2 * MPNN_H; i += 256) {
-    unsafeAtomicAdd(dvec + i, acc1[i]);
-    unsafeAtomicAdd(dvec + 2 * MPNN_H + i, acc2[i]);
-    if (i < MPNN_H) unsafeAtomicAdd(dvec + 4 * MPNN_H + i, accb3[i]);
+    vp[i] = ((acc1_w[0][i] + acc1_w[1][i]) + acc1_w[2][i]) + acc1_w[3][i];
+    vp[2 * MPNN_H + i] = ((acc2_w[0][i] + acc2_w[1][i]) + acc2_w[2][i]) + acc2_w[3][i];
+    if (i < MPNN_H) vp[4 * MPNN_H + i] = ((accb3_w[0][i] + accb3_w[1][i]) + accb3_w[2][i]) + accb3_w[3][i];
   }
 }
 
@@ -606,17 +619,23 @@ extern "C" int mpnn_node_update_bwd(const float* dY, const float* dPQ_blocks, co
                                     const float* WprojT_packed, int nproj, const float* WoutT_packed,
                                     const float* WinT_packed, const float* W3T_packed, int n_nodes, float* d_hV_in,
                                     float* d_gsum, float* x1, float* hid, float* d_a, float* d_o, float* d_dh,
-                                    float* dvec640, float p_drop, uint32_t drop_seed, void* stream) {
+                                    float* dvec640, float p_drop, uint32_t drop_seed, float* workspace,
+                                    int workspace_floats, void* stream) {
   MPNN_CHECK_ARG(x1pre && a_pre && x2pre && mask && ln1_w && ln1_b && ln2_w && WoutT_packed && WinT_packed &&
-                     W3T_packed && d_hV_in && d_gsum && x1 && hid && d_a && d_o && d_dh && dvec640 && n_nodes > 0,
+                     W3T_packed && d_hV_in && d_gsum && x1 && hid && d_a && d_o && d_dh && dvec640 && workspace &&
+                     n_nodes > 0,
                  "mpnn_node_update_bwd: bad arguments");
+  const int n_wg = (n_nodes + 63) / 64;
+  MPNN_CHECK_ARG((long long)workspace_floats >= (long long)n_wg * 5 * MPNN_H,
+                 "mpnn_node_update_bwd: workspace too small (640 floats per 64 nodes)");
   MPNN_CHECK_ARG(nproj == 0 || (WprojT_packed && dPQ_blocks), "mpnn_node_update_bwd: projections need WprojT and dPQ");
   MPNN_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mpnn_node_update_bwd: dropout probability must be in [0, 1)");
   hipLaunchKernelGGL(k_node_update_bwd, dim3((n_nodes + 63) / 64), dim3(256), 0, (hipStream_t)stream, dY, dPQ_blocks,
                      x1pre, a_pre, x2pre, cnt, cnt_const, mask, ln1_w, ln1_b, ln2_w, 1.0f / scale,
                      (const h8*)WprojT_packed, nproj, (const h8*)WoutT_packed, (const h8*)WinT_packed,
-                     (const h8*)W3T_packed, n_nodes, d_hV_in, d_gsum, x1, hid, d_a, d_o, d_dh, dvec640,
+                     (const h8*)W3T_packed, n_nodes, d_hV_in, d_gsum, x1, hid, d_a, d_o, d_dh, workspace,
                      make_drop(p_drop, drop_seed));
+  launch_partials_reduce(workspace, n_wg, 5 * MPNN_H, 5 * MPNN_H, dvec640, 1, (hipStream_t)stream);
   MPNN_LAUNCH_CHECK();
 }
 
@@ -628,7 +647,7 @@ static int launch_node_wgrads(const WgradJobs& jb, int n_rows, float* workspace,
   while ((n_rows + rows - 1) / rows > (max_x < 256 ? max_x : 256)) rows *= 2;
   const int nx = (n_rows + rows - 1) / rows;
   hipLaunchKernelGGL(MPNN_NODE_WGRAD_KERNEL, dim3(nx, nblk), dim3(256), 0, st, jb, n_rows, rows, workspace);
-  hipLaunchKernelGGL(k_node_wgrad_reduce, dim3((NW_PART + 255) / 256, 4 * nblk), dim3(256), 0, st, workspace, nx, jb);
+  hipLaunchKernelGGL(k_node_wgrad_reduce, dim3((NW_PART + 63) / 64, nblk), dim3(256), 0, st, workspace, nx, jb);
   MPNN_LAUNCH_CHECK();
 }
 

@@ -779,7 +779,9 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
         hVs = [enc["hV"].repeat(n_samples, 1)] + [torch.empty(Ns, H, device=dev) for _ in range(n_dec)]
         PA = [PQenc[:, base:base + 2 * H].repeat(n_samples, 1)] + \
              [torch.empty(Ns, 2 * H, device=dev) for _ in range(n_dec - 1)]
-        gsum = torch.zeros(Ns, H, device=dev, dtype=torch.float32)  # accumulated by atomics, re-zeroed by the node kernel
+        # "split" launches only: per-tile neighbour sums [residue][4][128], written by the message kernel, added in tile
+        # order by the node kernel (sized below, once the mode is known)
+        gsum = None
         import ctypes
         A_rows = (ctypes.c_void_p * n_dec)(*[t.data_ptr() for t in PA])
         A_ld = (ctypes.c_int * n_dec)(*([2 * H] * n_dec))
@@ -792,13 +794,13 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
             grp = pw.g_dec[l]
             msg = [ptr(enc["hE"]), ptr(PA[l]), 2 * H, 0, ptr(PA[l]), 2 * H, H, ptr(PQenc), PQenc.shape[1],
                    base + 2 * H + H * l, ptr(rank), ptr(enc["E_idx32"]), ptr(mask_s), ptr(enc["edge_mask"]),
-                   ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"]), None, 0, N, L, K, ptr(gsum), st]
-            node = [ptr(hVs[l]), ptr(gsum), float(K), ptr(mask_s), ptr(lw["W3"]), ptr(lw["b3"]), ptr(lw["ln1w"]),
+                   ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"]), None, 0, N, L, K, None, st]
+            node = [ptr(hVs[l]), None, (K + 15) // 16, float(K), ptr(mask_s), ptr(lw["W3"]), ptr(lw["b3"]), ptr(lw["ln1w"]),
                     ptr(lw["ln1b"]), ptr(lw["Win"]), ptr(lw["bin"]), ptr(lw["Wout"]), ptr(lw["bout"]), ptr(lw["ln2w"]),
                     ptr(lw["ln2b"]), lw["scale"], ptr(grp[0]), ptr(grp[1]), grp[2], None, 0, ptr(hVs[l + 1]),
                     ptr(PA[l + 1]) if grp[2] else None, st]
             # both in one launch (mpnn_dec_layer_subset): the message arguments without gsum, then the node update's
-            layer = msg[:22] + [node[0], node[2]] + node[4:18] + [node[20], node[21], st]
+            layer = msg[:22] + [node[0], node[3]] + node[5:19] + [node[21], node[22], st]
             layer[30] = ptr(lw["Wout8"])  # the fused kernel splits the FFN over eight waves: W_out in 64-column blocks
             plans.append((msg, node, layer))
         head = [ptr(hVs[n_dec]), ptr(pw.Wlogit), ptr(pw.blogit), ptr(lb), pw.n_letters, None, 0, float(temperature),
@@ -821,6 +823,10 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
             mode = "layer"
         if os.environ.get("MPNN_SAMPLE_UNFUSED") == "1" or K > 48:
             mode = "split"  # the fused level kernels give a workgroup four residues x three column tiles (K <= 48)
+        if mode == "split":
+            gsum = torch.empty(Ns, 4, H, device=dev, dtype=torch.float32)
+            for msg, node, _ in plans:
+                msg[22], node[1] = ptr(gsum), ptr(gsum)
         f_layer = getattr(lib, _lib.entry("mpnn_dec_layer_subset"))
         f_last = getattr(lib, _lib.entry("mpnn_dec_layer_sample_subset"))
         last = plans[-1][2][:35] + [plans[-1][2][38]] + head[1:5] + head[7:19] + [st]
@@ -896,7 +902,7 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
                     rc = rc or f_layer(*layer)
                 else:
                     msg[17], msg[18] = p_nodes, cnt_l
-                    node[18], node[19] = p_nodes, cnt_l
+                    node[19], node[20] = p_nodes, cnt_l
                     rc = rc or f_msg(*msg) or f_node(*node)
             head[5], head[6] = p_nodes, cnt_l
             rc = rc or f_head(*head)

@@ -29,11 +29,16 @@ def _check(tensors, what):
 
 
 def grad_sumsq(grads):
-    """Device scalar: sum of squares over all gradient elements (one zero-fill + ceil(n / 48) launches)."""
+    """Device scalar: sum of squares over all gradient elements (ceil(n / 48) + 1 launches; per-workgroup partials are
+    added in a fixed tree, so the value - and the clip coefficient derived from it - is the same on every run)."""
     _check(grads, "gradients")
-    out = torch.zeros(1, device=grads[0].device, dtype=torch.float32)
-    numel = (ctypes.c_int * len(grads))(*[g.numel() for g in grads])
-    call("mpnn_grad_sumsq", len(grads), _tables(grads), numel, ptr(out), stream_ptr())
+    dev = grads[0].device
+    out = torch.empty(1, device=dev, dtype=torch.float32)
+    sizes = [g.numel() for g in grads]
+    numel = (ctypes.c_int * len(grads))(*sizes)
+    need = sum(((max(sizes[k:k + 48]) + 2047) // 2048) * len(sizes[k:k + 48]) for k in range(0, len(sizes), 48))
+    ws = torch.empty(need, device=dev, dtype=torch.float32)
+    call("mpnn_grad_sumsq", len(grads), _tables(grads), numel, ptr(out), ptr(ws), need, stream_ptr())
     return out
 
 

@@ -42,21 +42,29 @@ class Graph:
         self.KT = (K + 15) // 16
         self.Kp = 16 * self.KT
         self.E_idx64, self.E_idx32, self.mask, self.edge_mask = E_idx64, E_idx32, mask, edge_mask
-        self.max_chunks = (self.N * K) // 32 + self.N
+        self.max_chunks = (self.N * K) // self.GATHER_CHUNK + self.N
         self.rank = None
         self.sel = None
         # inverse lists (edges grouped by the node they gather from, in the order of a stable sort by target)
         n_edges = self.N * K
         self.inv_ptr = torch.empty(self.N + 1, device=dev, dtype=torch.int32)
         self.chunk_ptr = torch.empty(self.N + 1, device=dev, dtype=torch.int32)
+        self.chunk_node = torch.empty(self.max_chunks, device=dev, dtype=torch.int32)
         self.inv_row = torch.empty(n_edges, device=dev, dtype=torch.int32)
         if K <= L and self.N * L <= self.SLOT_MAP_LIMIT:
-            if E_idx32 is None:   # stand-alone use (tests): the padded int32 form mpnn_knn_topk would have written
+            trusted = E_idx32 is not None   # mpnn_knn_topk's own lists: in range, a residue's neighbours distinct
+            if E_idx32 is None:   # stand-alone use (tests, caller-supplied lists): the padded int32 form
                 E_idx32 = torch.zeros(self.N, self.Kp, device=dev, dtype=torch.int32)
                 E_idx32[:, :K] = E_idx64.reshape(self.N, K)
             slot_map = torch.empty(self.N * L, device=dev, dtype=torch.uint8)
+            status = None if trusted else torch.zeros(1, device=dev, dtype=torch.int32)
             call("mpnn_inverse_lists", ptr(E_idx32), B, L, K, ptr(slot_map), ptr(self.inv_ptr), ptr(self.chunk_ptr),
-                 ptr(self.inv_row), stream_ptr())
+                 ptr(self.chunk_node), ptr(self.inv_row), ptr(status), stream_ptr())
+            if status is not None and int(status) != 0:
+                # a neighbour listed twice (or out of range): the slot map holds one edge per (target, centre) pair
+                if int(E_idx64.min()) < 0 or int(E_idx64.max()) >= L:
+                    raise ValueError(f"E_idx: neighbour ids must lie in [0, {L})")
+                self._lists_by_sort(E_idx64)
         else:
             self._lists_by_sort(E_idx64)
 
@@ -72,6 +80,7 @@ class Graph:
         return torch.arange(self.N, device=self.E_idx64.device).view(-1, 1).expand(-1, self.K).reshape(-1)
 
     SLOT_MAP_LIMIT = 1 << 30   # bytes of scratch mpnn_inverse_lists may take (B L^2); above: sort-based construction
+    GATHER_CHUNK = 64          # list entries per work unit of mpnn_gather_rows (mpnn_edge_bwd.hip)
 
     def _lists_by_sort(self, E_idx64):
         """The same lists from ATen ops (a stable sort of the edges by target): for batches whose B L^2-byte slot map
@@ -85,8 +94,13 @@ class Graph:
         # (torch.bincount synchronises with the host to size its output; scatter_add does not)
         counts = torch.zeros(self.N, device=dev, dtype=torch.int64).scatter_add_(0, dest, torch.ones_like(dest))
         self.inv_ptr = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]).to(torch.int32).contiguous()
-        chunks = (counts + 31) // 32  # mpnn_gather_rows works on chunks of <= 32 list entries (hub residues!)
-        self.chunk_ptr = torch.cat([chunks.new_zeros(1), torch.cumsum(chunks, 0)]).to(torch.int32).contiguous()
+        # mpnn_gather_rows works on chunks of <= 64 list entries (hub residues!), at least one per node
+        chunks = torch.clamp((counts + self.GATHER_CHUNK - 1) // self.GATHER_CHUNK, min=1)
+        ends = torch.cumsum(chunks, 0)
+        self.chunk_ptr = torch.cat([chunks.new_zeros(1), ends]).to(torch.int32).contiguous()
+        # (searchsorted instead of repeat_interleave: no host read of the total; entries past the last chunk are unused)
+        self.chunk_node = torch.searchsorted(ends, torch.arange(self.max_chunks, device=dev), right=True) \
+            .clamp_(max=self.N - 1).to(torch.int32).contiguous()
 
     def set_order(self, rank):
         """rank [N] int32 decoding rank; sel = 1 where the edge read the encoder block (neighbour not yet decoded)."""
@@ -125,10 +139,11 @@ def _wgrad(A, a_rows, amax, Bfrag, b_gelu, g, want_bias):
 
 
 def _gather(rows, g, sel):
-    outA = torch.zeros(g.N, H, device=rows.device, dtype=torch.float32)
-    outB = torch.zeros_like(outA) if sel is not None else None
-    call("mpnn_gather_rows", ptr(rows), ptr(g.inv_ptr), ptr(g.inv_row), ptr(sel), ptr(g.chunk_ptr), g.N, g.max_chunks,
-         ptr(outA), ptr(outB), stream_ptr())
+    outA = torch.empty(g.N, H, device=rows.device, dtype=torch.float32)   # every row is written by the kernel
+    outB = torch.empty_like(outA) if sel is not None else None
+    part = torch.empty(g.max_chunks * 2 * H, device=rows.device, dtype=torch.float32)
+    call("mpnn_gather_rows", ptr(rows), ptr(g.inv_ptr), ptr(g.inv_row), ptr(sel), ptr(g.chunk_ptr), ptr(g.chunk_node),
+         g.N, g.max_chunks, ptr(outA), ptr(outB), ptr(part), stream_ptr())
     return outA, outB
 
 
@@ -178,16 +193,38 @@ def _workspace(dev):
     return ws
 
 
+def _pow2_scale(t):
+    """Exact power of two that brings max |t| to [2^12, 2^13) (1 for an all-zero tensor), as a device scalar: the
+    library's GEMMs split their operands into f16 hi + lo halves, which resolve only 3e-8 ABSOLUTE below 6e-5 -
+    gradient-sized operands (loss / 2000) are scaled up first and the product scaled back (mpnn_bwd_common.h does the
+    same inside the backward kernels).  No host synchronisation."""
+    amax = t.detach().abs().max()
+    e = torch.floor(torch.log2(torch.clamp(amax, min=1e-38)))
+    return torch.where(amax > 0, torch.exp2(12.0 - e), torch.ones_like(amax))
+
+
+def _linear_rows(x, Wp, bias):
+    """y [rows, 128] = x [rows, 128] Wp^T (+ bias) on mpnn_linear_rows (Wp: one split-packed 128 x 128 block)."""
+    x = x.contiguous()
+    y = torch.empty(x.shape[0], H, device=x.device, dtype=torch.float32)
+    if x.shape[0]:
+        call("mpnn_linear_rows", ptr(x), H, H, ptr(Wp), ptr(bias), x.shape[0], ptr(y), stream_ptr())
+    return y
+
+
 class LinearFn(torch.autograd.Function):
-    """F.linear on [rows, in] whose weight / bias gradients come from mpnn_node_wgrad (split-K fp32 MFMA + atomics):
-    the library GEMM for this 'tiny output, 10^4-long reduction' shape takes 91 us per call."""
+    """nn.Linear(128 -> 128) on [rows, 128] entirely on the library: forward and the input gradient on
+    mpnn_linear_rows (split-f16 MFMA, fp32-class), weight / bias gradients on mpnn_node_wgrad.  (Round 2 used
+    F.linear / `dy @ W` here: hipBLASLt launches on the training path.)"""
 
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, x, W, b):
+        assert W.shape == (H, H) and x.shape[-1] == H, "LinearFn serves the path's 128 x 128 blocks"
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
-        return F.linear(x, W, b)
+        wp, = _pack_blocks([(W, False)])
+        return _linear_rows(x.detach().float(), wp, b.detach().float().contiguous() if b is not None else None)
 
     @staticmethod
     @custom_bwd(device_type="cuda")
@@ -195,7 +232,11 @@ class LinearFn(torch.autograd.Function):
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
         x = x.contiguous()
-        dx = dy @ W if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt, = _pack_blocks([(W, True)])
+            sc = _pow2_scale(dy)
+            dx = _linear_rows(dy * sc, wt, None) / sc
         dW = _zeros(dy.device, *W.shape)
         db = _zeros(dy.device, W.shape[0]) if ctx.has_bias else None
         ws = _workspace(dy.device)
@@ -206,6 +247,31 @@ class LinearFn(torch.autograd.Function):
 
 def linear(x, W, b=None):
     return LinearFn.apply(x, W, b)
+
+
+class TableRowsFn(torch.autograd.Function):
+    """rows[n] = table[idx[n]] (the decoder's per-letter sequence term, reference :478-479 h_S = W_s(S) followed by its
+    W1 column block).  Backward: d table = one_hot(idx)^T d rows as a node-level weight gradient on mpnn_node_wgrad -
+    a fixed summation order, where ATen's index_add / embedding backward meet rows by atomics."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, table, idx, onehot):
+        ctx.save_for_backward(onehot)
+        ctx.n_rows = table.shape[0]
+        return table.index_select(0, idx)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, d_rows):
+        (onehot,) = ctx.saved_tensors
+        d_rows = d_rows.contiguous()
+        dev = d_rows.device
+        dWt = _zeros(dev, H, onehot.shape[1])      # [feature][letter]
+        ws = _workspace(dev)
+        call("mpnn_node_wgrad", ptr(d_rows), H, H, ptr(onehot), onehot.shape[1], ctx.n_rows, d_rows.shape[0], ptr(dWt),
+             onehot.shape[1], None, ptr(ws), ws.numel(), stream_ptr())
+        return dWt[:, :ctx.n_rows].t().contiguous(), None, None
 
 
 class GradSlot:
@@ -307,9 +373,11 @@ class EdgeUpdateFn(torch.autograd.Function):
         dln = _zeros(dev, 2 * H)
         amax = _zeros(dev, 3)
         w3t, w2t, w1t = _pack_blocks([(W13, True), (W12, True), (W11b, True)])
+        ws = _workspace(dev)
         call("mpnn_enc_edge_update_bwd", ptr(dy), ptr(z), ptr(a2), ptr(a1), ptr(lnw.detach().contiguous()),
              ptr(w3t), ptr(w2t), ptr(w1t),
-             g.B, g.L, g.K, ptr(dz), ptr(da2), ptr(rows), ptr(dP), ptr(dE), ptr(dln), ptr(amax), ctx.drop[0], ctx.drop[1], stream_ptr())
+             g.B, g.L, g.K, ptr(dz), ptr(da2), ptr(rows), ptr(dP), ptr(dE), ptr(dln), ptr(amax), ctx.drop[0], ctx.drop[1],
+             ptr(ws), ws.numel(), stream_ptr())
         dQ, _ = _gather(rows, g, None)
         dW13, db13 = _wgrad(dz, False, amax[0:1], a2, True, g, True)
         dW12, db12 = _wgrad(da2, False, amax[1:2], a1, True, g, True)
@@ -376,8 +444,9 @@ class FeaturesFn(torch.autograd.Function):
         dln = _zeros(dev, 2 * H)
         amax = _zeros(dev, 2)
         wet, = _pack_blocks([(We, True)])
+        ws = _workspace(dev)
         call("mpnn_edge_features_bwd", ptr(dhE), ptr(E0), ptr(lnw.detach().contiguous()), ptr(wet), g.B, g.L, g.K,
-             ptr(dE0), ptr(dln), ptr(amax), st)
+             ptr(dE0), ptr(dln), ptr(amax), ptr(ws), ws.numel(), st)
         dWe, dbe = _wgrad(dhE, False, amax[0:1], E, False, g, True)
         nrbf = na * na * 16
         nch = (na * na + 5 + 7) // 8
@@ -390,8 +459,9 @@ class FeaturesFn(torch.autograd.Function):
         G = dF[:, nrbf:nrbf + 66]                                           # sum of dE0 rows per position bucket
         W = Wemb.detach()
         npos = W.shape[1] - nrbf
-        dT = G.t() @ W[:, :npos]                                            # gradient of the 66 x 16 embedding table
-        dWemb = torch.cat([G @ table.view(66, 16), dF[:, :nrbf]], dim=1)
+        # two 128 x 66 x 16 contractions as broadcast products + ATen tree sums (a library GEMM launch each otherwise)
+        dT = (G.unsqueeze(2) * W[:, :npos].unsqueeze(1)).sum(0)             # gradient of the 66 x 16 embedding table
+        dWemb = torch.cat([(G.unsqueeze(2) * table.view(1, 66, 16)).sum(1), dF[:, :nrbf]], dim=1)
         return (None, None, None, None, None, None, dT.t().contiguous(), dT.sum(0), dWemb, dln[:H], dln[H:], dWe, dbe)
 
 
@@ -482,10 +552,12 @@ class NodeUpdateFn(torch.autograd.Function):
         x1, d_o, d_dh = torch.empty(N, H, device=dev), torch.empty(N, H, device=dev), torch.empty(N, H, device=dev)
         hid, d_a = torch.empty(N, 4 * H, device=dev), torch.empty(N, 4 * H, device=dev)
         dvec = _zeros(dev, 5 * H)
+        ws = _workspace(dev)
         call("mpnn_node_update_bwd", ptr(dY), ptr(dPQb), ptr(x1pre), ptr(a_pre), ptr(x2pre), ptr(cnt), 0.0, ptr(mask),
              ptr(ln1w.detach().contiguous()), ptr(ln1b.detach().contiguous()), ptr(ln2w.detach().contiguous()),
              float(scale), ptr(wprojT), nproj, ptr(woutT), ptr(winT), ptr(w3T), N, ptr(d_hV_in), ptr(d_gsum), ptr(x1),
-             ptr(hid), ptr(d_a), ptr(d_o), ptr(d_dh), ptr(dvec), float(p_drop), int(seed), stream_ptr())
+             ptr(hid), ptr(d_a), ptr(d_o), ptr(d_dh), ptr(dvec), float(p_drop), int(seed), ptr(ws), ws.numel(),
+             stream_ptr())
         res = _node_wgrad_batch([(d_dh, gsum, False), (d_a, x1, True), (d_o, hid, True)] +
                                 [(dPQb[p], hV_out, ctx.has_bias[p]) for p in range(nproj)])
         (dW3, _), (dWin, dbin), (dWout, dbout) = res[:3]
@@ -580,11 +652,15 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
             rank = torch.zeros(N, device=dev, dtype=torch.int32)
             call("mpnn_order_rank", ptr(order), B, L, ptr(rank), stream_ptr())
             g.set_order(rank)
-        hS = model.W_s(S.reshape(-1))
+        # sequence term W1c W_s[S] of the decoded neighbours as a 21-row table per layer (the inference path's TS):
+        # TS_l = W_s W1c_l^T, rows picked by S
+        Sflat = S.reshape(-1)
+        n_vocab = model.W_s.weight.shape[0]
+        onehot = F.one_hot(Sflat, 32 * ((n_vocab + 31) // 32)).to(torch.float32)
         Pa, A0, Benc = proj[0], proj[1], proj[2:]
         for l, lyr in enumerate(dec):
             W1 = W1s[id(lyr)]
-            A = A0 + linear(hS, W1[2])      # sequence term W1c W_s[S] of the decoded neighbours
+            A = A0 + TableRowsFn.apply(linear(model.W_s.weight, W1[2]), Sflat, onehot)
             gsum, cnt = MessageFn.apply(g, slot, True, hE, Pa, A, Benc[l], W1[1], lyr.W2.weight, lyr.W2.bias)
             nxt = [(W1s[id(dec[l + 1])][0], dec[l + 1].W1.bias), (W1s[id(dec[l + 1])][3], None)] \
                 if l + 1 < len(dec) else []
@@ -623,8 +699,9 @@ class HeadFn(torch.autograd.Function):
         d_hV = torch.empty_like(hV)
         dW = _zeros(hV.device, n_letters, H)
         db = _zeros(hV.device, n_letters)
+        ws = _workspace(hV.device)
         call("mpnn_logits_log_softmax_bwd", ptr(d_logp), ptr(logp), ptr(hV), ptr(W), n_letters, N, ptr(d_hV), ptr(dW),
-             ptr(db), stream_ptr())
+             ptr(db), ptr(ws), ws.numel(), stream_ptr())
         return d_hV, dW, db
 
 
@@ -640,10 +717,11 @@ class SmoothedLossFn(torch.autograd.Function):
         N = lp.numel() // n_letters
         dev = lp.device
         loss = torch.empty(S.shape, device=dev, dtype=torch.float32)
-        total = torch.zeros((), device=dev, dtype=torch.float32)
+        total = torch.empty((), device=dev, dtype=torch.float32)
         d_lp = torch.empty_like(lp)
+        ws = torch.empty((N + 255) // 256, device=dev, dtype=torch.float32)
         call("mpnn_loss_smoothed", ptr(lp), ptr(S.contiguous()), ptr(mask.contiguous().float()), N, n_letters,
-             float(weight), 1.0 / 2000.0, ptr(loss), ptr(total), ptr(d_lp), stream_ptr())
+             float(weight), 1.0 / 2000.0, ptr(loss), ptr(total), ptr(d_lp), ptr(ws), ws.numel(), stream_ptr())
         ctx.save_for_backward(d_lp)
         ctx.mark_non_differentiable(loss)
         return loss, total

@@ -128,6 +128,24 @@ def test_low_temperature_is_argmax_and_seed_reproducible():
     assert not torch.equal(c["S"], a["S"])
 
 
+@pytest.mark.parametrize("mode", ["run", "run/head", "layer", "layer/head", "layer+draw", "level", "split"])
+def test_every_launch_mode_is_bit_reproducible(monkeypatch, mode):
+    """No sum of the sampler meets by atomics (a residue's column-tile sums are added in tile order, in LDS or from
+    per-tile rows in HBM): the same call twice returns the same sequences AND the same log-probs, bit for bit, in
+    every launch mode; k = 56 takes the four-tile split launches whatever the mode."""
+    from mpnn_amd.synthetic import synthetic_batch
+
+    monkeypatch.setenv("MPNN_SAMPLE_LAUNCHES", mode)
+    for k in (48, 56):
+        model = build(dict(k_neighbors=k, use_virtual_center=True))
+        b = {n: v.to("cuda") for n, v in synthetic_batch(B=2, L=90, seed=4, lengths=[90, 71], n_chains=2,
+                                                         design_fraction=0.7).items()}
+        args = (b["X"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
+        a = model.sample(*args, S_true=b["S"], n_samples=6, temperature=0.5, seed=11)
+        c = model.sample(*args, S_true=b["S"], n_samples=6, temperature=0.5, seed=11)
+        assert torch.equal(a["S"], c["S"]) and torch.equal(a["log_probs"], c["log_probs"]), (mode, k)
+
+
 def test_draw_frequencies_follow_the_model_distribution():
     """Residues decoded first see no sequence context: across samples with a FIXED order their letters are i.i.d. draws
     from one known distribution; compare frequencies over 4096 draws (256 samples x 16 first residues of equal
