@@ -274,11 +274,13 @@ int mpnn_logits_log_softmax(const float* hV, const float* Wout_packed, const flo
  * ------------------------------------------------------------------------------------------------------------ */
 
 /* Forward of mpnn_enc_message (dec = 0: Row = RowA[j], cnt written) or mpnn_dec_message (dec = 1: Row = RowA[j]
- * where rank[j] < rank[i], else RowB[j]) that also stores a1 = P + s (Row + W1b e) and a2 = W2 gelu(a1) + b2. */
+ * where rank[j] < rank[i], else RowB[j]) that also stores a1 = P + s (Row + W1b e) and a2 = W2 gelu(a1) + b2.
+ * w_valid != 0 (dec = 1 only, edge_mask required): the neighbour sum runs over the edges with edge_mask = 1 only, as
+ * mpnn_dec_message_valid's does (the edge-list model's Decoder, src/mpnn/models/protein_mpnn.py:203-217). */
 int mpnn_message_train(int dec, const float* hE_frag, const float* P, const float* RowA, const float* RowB,
                        const int32_t* rank, const int32_t* E_idx32, const float* mask, const float* edge_mask,
                        const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K,
-                       float* gsum, float* cnt, float* a1_frag, float* a2_frag, void* stream);
+                       float* gsum, float* cnt, float* a1_frag, float* a2_frag, int w_valid, void* stream);
 
 /* Forward of mpnn_enc_edge_update, out of place, storing a1', a2' and the pre-LayerNorm sum z (:90-95).
  * p_drop > 0 applies EncLayer.dropout3 (:94) to the MLP output: an element is kept when
@@ -292,11 +294,12 @@ int mpnn_enc_edge_update_train(const float* hE_frag, const float* P, const float
 
 /* Backward of the message MLP: given dgsum, writes da2 (fragment), s-scaled da1 rows, dP = sum_k da1, and
  * dE (+)= W1b^T (s da1).  W2T / W1bT are mpnn_pack_linear_split of the TRANSPOSED matrices.
- * amax2[0..1] (zero them first) receive max |da2| and max |da1 rows| as fp32: mpnn_edge_wgrad's A_absmax. */
+ * amax2[0..1] (zero them first) receive max |da2| and max |da1 rows| as fp32: mpnn_edge_wgrad's A_absmax.
+ * w_valid as given to mpnn_message_train. */
 int mpnn_message_bwd(int dec, const float* dgsum, const float* a1_frag, const float* a2_frag, const int32_t* E_idx32,
                      const float* mask, const float* edge_mask, const float* W2T_packed, const float* W1bT_packed,
                      int B, int L, int K, float* da2_frag, float* da1_rows, float* dP, float* dE_frag, int accumulate,
-                     float* amax2, void* stream);
+                     float* amax2, int w_valid, void* stream);
 
 /* Backward of the edge update: LayerNorm', W13^T, W12^T, W11b^T; dln[0:128] += d ln_w, dln[128:256] += d ln_b.
  * dE_frag may alias dy_frag.  amax3[0..2] (zero them first) receive max |dz|, |da2|, |da1 rows|.
@@ -349,12 +352,14 @@ int mpnn_inverse_sel(const int32_t* rank, const int32_t* inv_ptr, const int32_t*
                      unsigned char* sel, void* stream);
 
 /* Training forward of mpnn_edge_features: also stores the pre-LayerNorm embedding E0 and E = norm_edges(E0), both in
- * the fragment layout, for mpnn_edge_features_bwd / mpnn_edge_wgrad (:334-358, :464). */
+ * the fragment layout, for mpnn_edge_features_bwd / mpnn_edge_wgrad (:334-358, :464).  Wemb_bias [128] or NULL: a
+ * bias on the embedding before its LayerNorm (mpnn_edge_features_biased's form, the edge-list model's edge_mlp.0);
+ * its gradient is the column sum of dE0, i.e. mpnn_edge_wgrad's dbias output. */
 int mpnn_edge_features_train(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
                              const int64_t* chain_labels, const float* pos_table, const float* rbf_mu,
-                             const float* Wemb_packed, const float* ln_w, const float* ln_b, const float* We_packed,
-                             const float* We_bias, int B, int L, int K, int n_atoms, float* E0_frag, float* E_frag,
-                             float* hE_frag, void* stream);
+                             const float* Wemb_packed, const float* Wemb_bias, const float* ln_w, const float* ln_b,
+                             const float* We_packed, const float* We_bias, int B, int L, int K, int n_atoms,
+                             float* E0_frag, float* E_frag, float* hE_frag, void* stream);
 
 /* Featurizer backward: dE = W_e^T dhE0, dE0 = LayerNorm'(dE; E0).  WeT_packed = mpnn_pack_linear_split(W_e^T).
  * dln[0:128] += d norm_edges.weight, dln[128:256] += d norm_edges.bias; amax2 (zeroed) <- max |dhE0|, max |dE0|.

@@ -60,15 +60,15 @@ SIGNATURES = {
     "mpnn_occupancy_mlp": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "mpnn_logits_log_softmax": [_P, _P, _P, _I, _I, _P, _P],
     # training step (forward with saved pre-activations, backward, weight gradients)
-    "mpnn_message_train": [_I] + [_P] * 11 + [_I] * 3 + [_P] * 5,
+    "mpnn_message_train": [_I] + [_P] * 11 + [_I] * 3 + [_P] * 4 + [_I, _P],
     "mpnn_enc_edge_update_train": [_P] * 11 + [_I] * 3 + [_P] * 4 + [_F, ctypes.c_uint32, _P],
-    "mpnn_message_bwd": [_I] + [_P] * 8 + [_I] * 3 + [_P] * 4 + [_I, _P, _P],
+    "mpnn_message_bwd": [_I] + [_P] * 8 + [_I] * 3 + [_P] * 4 + [_I, _P, _I, _P],
     "mpnn_enc_edge_update_bwd": [_P] * 8 + [_I] * 3 + [_P] * 7 + [_F, ctypes.c_uint32, _P, _I, _P],
     "mpnn_edge_wgrad": [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P],
     "mpnn_gather_rows": [_P] * 6 + [_I, _I] + [_P] * 4,
     "mpnn_inverse_lists": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "mpnn_inverse_sel": [_P, _P, _P, _I, _I, _P, _P],
-    "mpnn_edge_features_train": [_P] * 11 + [_I, _I, _I, _I, _P, _P, _P, _P],
+    "mpnn_edge_features_train": [_P] * 12 + [_I, _I, _I, _I, _P, _P, _P, _P],
     "mpnn_edge_features_bwd": [_P] * 4 + [_I] * 3 + [_P] * 4 + [_I, _P],
     "mpnn_feature_chunks": [_P] * 5 + [_I] * 4 + [_P, _P],
     # autoregressive sampling

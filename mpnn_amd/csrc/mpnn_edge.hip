@@ -1575,10 +1575,11 @@ extern "C" int mpnn_message_train(int dec, const float* hE_frag, const float* P,
                                   const int32_t* rank, const int32_t* E_idx32, const float* mask,
                                   const float* edge_mask, const float* W1b_packed, const float* W2_packed,
                                   const float* b2, int B, int L, int K, float* gsum, float* cnt, float* a1_frag,
-                                  float* a2_frag, void* stream) {
+                                  float* a2_frag, int w_valid, void* stream) {
   MPNN_CHECK_ARG(hE_frag && P && RowA && E_idx32 && mask && W1b_packed && W2_packed && b2 && gsum && a1_frag && a2_frag,
                  "mpnn_message_train: null pointer");
   MPNN_CHECK_ARG(dec ? (RowB && rank) : (cnt != nullptr), "mpnn_message_train: decoder needs RowB and rank, encoder cnt");
+  MPNN_CHECK_ARG(!w_valid || (dec && edge_mask), "mpnn_message_train: w_valid is the decoder's form and needs edge_mask");
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64, "mpnn_message_train: bad sizes (K <= 64)");
   const int N = B * L, KT = (K + 15) / 16;
   dim3 grid(edge_grid(N, MPNN_MSG_WAVES)), block(MPNN_MSG_WAVES * 64);
@@ -1586,7 +1587,7 @@ extern "C" int mpnn_message_train(int dec, const float* hE_frag, const float* P,
     KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, true, true>), grid, block, 0, (hipStream_t)stream,
                                        (const f32x4*)hE_frag, P, 128, 0, RowA, 128, 0, RowB, 128, 0, rank, E_idx32,
                                        mask, edge_mask, (const h8*)W1b_packed, (const h8*)W2_packed, b2, N, L, K, gsum,
-                                       (float*)nullptr, (f32x4*)a1_frag, (f32x4*)a2_frag, N, 0));
+                                       (float*)nullptr, (f32x4*)a1_frag, (f32x4*)a2_frag, N, w_valid));
   } else {
     KT_DISPATCH(KT, hipLaunchKernelGGL((k_message<kKT, false, true>), grid, block, 0, (hipStream_t)stream,
                                        (const f32x4*)hE_frag, P, 128, 0, RowA, 128, 0, (const float*)nullptr, 0, 0,

@@ -65,7 +65,7 @@ k_message_bwd(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, con
               const int* __restrict__ E_idx, const float* __restrict__ mask, const float* __restrict__ edge_mask,
               const h8* __restrict__ W2T, const h8* __restrict__ W1bT, int N, int L, int K,
               f32x4* __restrict__ da2, float* __restrict__ da1_nat, float* __restrict__ dP, f32x4* __restrict__ dE,
-              int accumulate, unsigned* __restrict__ amax) {
+              int accumulate, unsigned* __restrict__ amax, int w_valid) {
   __shared__ h8 lds[2 * WSPLIT];
   __shared__ unsigned amax_l[2];
   lds_fill(lds, W2T, WSPLIT);
@@ -90,7 +90,7 @@ k_message_bwd(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, con
       if (edge_mask && e < K) em = edge_mask[(size_t)node * K + e];
       if (DEC) {
         s[c] = mi * em;
-        w[c] = e < K ? 1.0f : 0.0f;
+        w[c] = e < K ? (w_valid ? em : 1.0f) : 0.0f;  // w_valid: the sum ran over valid edges only (sparse variant)
       } else {
         s[c] = 1.0f;
         w[c] = e < K ? mi * mask[b * L + E_idx[(size_t)node * Kp + e]] * em : 0.0f;
@@ -739,11 +739,12 @@ extern "C" int mpnn_message_bwd(int dec, const float* dgsum, const float* a1_fra
                                 const int32_t* E_idx32, const float* mask, const float* edge_mask,
                                 const float* W2T_packed, const float* W1bT_packed, int B, int L, int K,
                                 float* da2_frag, float* da1_rows, float* dP, float* dE_frag, int accumulate,
-                                float* amax2, void* stream) {
+                                float* amax2, int w_valid, void* stream) {
   MPNN_CHECK_ARG(dgsum && a1_frag && a2_frag && E_idx32 && mask && W2T_packed && W1bT_packed && da2_frag &&
                      da1_rows && dP && dE_frag && amax2,
                  "mpnn_message_bwd: null pointer");
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64, "mpnn_message_bwd: bad sizes (K <= 64)");
+  MPNN_CHECK_ARG(!w_valid || (dec && edge_mask), "mpnn_message_bwd: w_valid is the decoder's form and needs edge_mask");
   const int N = B * L, KT = (K + 15) / 16;
   dim3 grid(edge_grid(N, MPNN_BWD_WAVES)), block(MPNN_BWD_WAVES * 64);
   if (dec) {
@@ -751,13 +752,13 @@ extern "C" int mpnn_message_bwd(int dec, const float* dgsum, const float* a1_fra
                 hipLaunchKernelGGL((k_message_bwd<kKT, true>), grid, block, 0, (hipStream_t)stream, dgsum,
                                    (const f32x4*)a1_frag, (const f32x4*)a2_frag, E_idx32, mask, edge_mask,
                                    (const h8*)W2T_packed, (const h8*)W1bT_packed, N, L, K, (f32x4*)da2_frag, da1_rows,
-                                   dP, (f32x4*)dE_frag, accumulate, (unsigned*)amax2));
+                                   dP, (f32x4*)dE_frag, accumulate, (unsigned*)amax2, w_valid));
   } else {
     KT_DISPATCH(KT,
                 hipLaunchKernelGGL((k_message_bwd<kKT, false>), grid, block, 0, (hipStream_t)stream,
                                    dgsum, (const f32x4*)a1_frag, (const f32x4*)a2_frag, E_idx32, mask, edge_mask,
                                    (const h8*)W2T_packed, (const h8*)W1bT_packed, N, L, K, (f32x4*)da2_frag, da1_rows,
-                                   dP, (f32x4*)dE_frag, accumulate, (unsigned*)amax2));
+                                   dP, (f32x4*)dE_frag, accumulate, (unsigned*)amax2, 0));
   }
   MPNN_LAUNCH_CHECK();
 }

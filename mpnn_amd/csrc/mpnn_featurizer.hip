@@ -940,9 +940,9 @@ extern "C" int MPNN_API(mpnn_edge_features_biased)(const float* atoms, const int
 #ifndef MPNN_FAST
 extern "C" int mpnn_edge_features_train(const float* atoms, const int32_t* E_idx32, const int64_t* residue_idx,
                                         const int64_t* chain_labels, const float* pos_table, const float* rbf_mu,
-                                        const float* Wemb_packed, const float* ln_w, const float* ln_b,
-                                        const float* We_packed, const float* We_bias, int B, int L, int K, int n_atoms,
-                                        float* E0_frag, float* E_frag, float* hE_frag, void* stream) {
+                                        const float* Wemb_packed, const float* Wemb_bias, const float* ln_w,
+                                        const float* ln_b, const float* We_packed, const float* We_bias, int B, int L,
+                                        int K, int n_atoms, float* E0_frag, float* E_frag, float* hE_frag, void* stream) {
   MPNN_CHECK_ARG(atoms && E_idx32 && residue_idx && chain_labels && pos_table && rbf_mu && Wemb_packed && ln_w &&
                      ln_b && We_packed && We_bias && hE_frag && E0_frag && E_frag,
                  "mpnn_edge_features_train: null pointer");
@@ -952,10 +952,10 @@ extern "C" int mpnn_edge_features_train(const float* atoms, const int32_t* E_idx
   hipStream_t s = (hipStream_t)stream;
   const long long *ri = (const long long*)residue_idx, *cl = (const long long*)chain_labels;
   switch (KT) {
-    case 1: return launch_edge_features<1>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag);
-    case 2: return launch_edge_features<2>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag);
-    case 3: return launch_edge_features<3>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag);
-    default: return launch_edge_features<4>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag);
+    case 1: return launch_edge_features<1>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag, Wemb_bias);
+    case 2: return launch_edge_features<2>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag, Wemb_bias);
+    case 3: return launch_edge_features<3>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag, Wemb_bias);
+    default: return launch_edge_features<4>(n_atoms, atoms, E_idx32, ri, cl, pos_table, rbf_mu, Wemb_packed, ln_w, ln_b, We_packed, We_bias, N, L, K, nullptr, hE_frag, s, E0_frag, E_frag, Wemb_bias);
   }
 }
 #endif

@@ -3,8 +3,10 @@ src/mpnn/models/protein_mpnn.py (flat node tensors + a `batch` vector, k-NN / ra
 aggregation over an edge list).  SURVEY.md section 8f, row N4.
 
 Same constructor, same `forward` signature and the same state_dict keys as the reference class, so a checkpoint of the
-reference loads with `load_state_dict`.  Inference only (no autograd graph is built); `forward` takes one extra,
-optional argument `decoding_order` because the reference draws the order inside the call (protein_mpnn.py:30-31).
+reference loads with `load_state_dict`.  `forward` takes one extra, optional argument `decoding_order` because the
+reference draws the order inside the call (protein_mpnn.py:30-31).  With grad mode on (training, or fine-tuning in eval
+mode) the call builds an autograd graph over the dense model's backward kernels (`_forward_train`: backbone noise
+:461-462, the five dropouts :136-144 / :198-200); under `torch.no_grad()` it runs the inference kernels.
 
 How the edge list maps onto the dense kernels (nothing here is a second implementation of the arithmetic):
   * nodes are scattered into a padded [B, Lmax] batch; every residue owns a neighbour list of K slots
@@ -337,9 +339,16 @@ class ProteinMPNN(nn.Module):
         """protein_mpnn.py:450-515.  decoding_order (optional, [B, Lmax] permutations of the padded rows) replaces the
         order the reference draws at :30-31; without it the same distribution is drawn here."""
         _require_device(x, "x")
+        # autograd semantics as for any nn.Module (and as mpnn_amd.ProteinMPNN): with grad mode on and trainable
+        # parameters the differentiable path runs - in eval mode too (no dropout, no noise); inference callers use
+        # torch.no_grad()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            with torch.autocast(device_type="cuda", enabled=False):
+                return self._forward_train(x, chain_seq_label, mask, chain_mask_all, residue_idx, chain_encoding_all,
+                                           batch, decoding_order)
         if self.training:
-            raise RuntimeError("mpnn_amd.sparse.ProteinMPNN runs inference only (call .eval()); train the dense model "
-                               "(mpnn_amd.ProteinMPNN), whose kernels have backward passes")
+            raise RuntimeError("mpnn_amd.sparse.ProteinMPNN in training mode needs grad mode on (its dropout / backbone "
+                               "noise live on the differentiable path); call .eval() for inference under no_grad")
         guard = numerics_guard(self, x.device)
         guard.poll()
         _lib.set_precision(self.precision)
@@ -360,10 +369,10 @@ class ProteinMPNN(nn.Module):
             g.check()
         return self
 
-    def _forward(self, x, S, mask, chain_mask_all, residue_idx, chain_encoding_all, batch, decoding_order):
+    def _dense_inputs(self, x, S, mask, chain_mask_all, residue_idx, chain_encoding_all, batch, noise_eps=0.0):
+        """Flat node tensors -> the padded [B * Lmax] layout of the dense kernels.
+        -> (B, L, slot, scatter, Xd, maskd, ridx, chain, Sd, maskf)"""
         dev = x.device
-        st = stream_ptr()
-        pw = _packed(self)
         n = x.shape[0]
         if x.dim() != 3 or x.shape[1] < 4 or x.shape[2] != 3:
             raise ValueError("x must be [n, 4, 3] (N, CA, C, O)")
@@ -380,13 +389,37 @@ class ProteinMPNN(nn.Module):
             out[slot] = src.to(dtype)
             return out
 
+        xv = _f32(x[:, :4])
+        if noise_eps > 0:   # :461-462
+            xv = xv + noise_eps * torch.randn_like(xv)
         # unresolved residues keep whatever coordinates they came with in the reference, which never reads them
-        xv = torch.where((maskf > 0).view(n, 1, 1), _f32(x[:, :4]), torch.zeros((), device=dev))
+        xv = torch.where((maskf > 0).view(n, 1, 1), xv, torch.zeros((), device=dev))
         Xd = scatter(xv, torch.float32)
         maskd = scatter(maskf, torch.float32)
         ridx = scatter(_i64(residue_idx), torch.int64)
         chain = scatter(_i64(chain_encoding_all), torch.int64)
         Sd = scatter(_i64(S), torch.int64)
+        return B, L, slot, scatter, Xd, maskd, ridx, chain, Sd, maskf
+
+    def _decoding_order(self, decoding_order, scatter, chain_mask_all, maskf, B, L, dev):
+        if decoding_order is not None:
+            order = _i64(decoding_order)
+            if tuple(order.shape) != (B, L):
+                raise ValueError(f"decoding_order must be [{B}, {L}] (the padded batch)")
+            if not bool((torch.sort(order, dim=-1).values == torch.arange(L, device=dev)).all()):
+                raise ValueError("every row of decoding_order must be a permutation of 0..Lmax-1")
+            return order
+        # :27-31 (padding rows carry 0, as to_dense_batch fills them)
+        key = scatter(_f32(chain_mask_all) * maskf, torch.float32).view(B, L)
+        return torch.argsort((key + 0.0001) * torch.abs(torch.randn(B, L, device=dev)))
+
+    def _forward(self, x, S, mask, chain_mask_all, residue_idx, chain_encoding_all, batch, decoding_order):
+        dev = x.device
+        st = stream_ptr()
+        pw = _packed(self)
+        B, L, slot, scatter, Xd, maskd, ridx, chain, Sd, maskf = self._dense_inputs(
+            x, S, mask, chain_mask_all, residue_idx, chain_encoding_all, batch)
+        N = B * L
         if int(pw.n_vocab) <= 0:
             raise ValueError("empty vocabulary")
 
@@ -444,16 +477,7 @@ class ProteinMPNN(nn.Module):
                  K, st)
 
         if n_dec:
-            if decoding_order is not None:
-                order = _i64(decoding_order)
-                if tuple(order.shape) != (B, L):
-                    raise ValueError(f"decoding_order must be [{B}, {L}] (the padded batch)")
-                if not bool((torch.sort(order, dim=-1).values == torch.arange(L, device=dev)).all()):
-                    raise ValueError("every row of decoding_order must be a permutation of 0..Lmax-1")
-            else:
-                # :27-31 (padding rows carry 0, as to_dense_batch fills them)
-                key = scatter(_f32(chain_mask_all) * maskf, torch.float32).view(B, L)
-                order = torch.argsort((key + 0.0001) * torch.abs(torch.randn(B, L, device=dev)))
+            order = self._decoding_order(decoding_order, scatter, chain_mask_all, maskf, B, L, dev)
             rank = torch.zeros(N, device=dev, dtype=torch.int32)
             call("mpnn_order_rank", ptr(order), B, L, ptr(rank), st)
             degree = valid.sum(-1).reshape(N).contiguous()
@@ -468,4 +492,110 @@ class ProteinMPNN(nn.Module):
 
         lp = torch.empty(N, pw.n_letters, device=dev, dtype=torch.float32)
         call("mpnn_logits_log_softmax", ptr(hV), ptr(pw.Wlogit), ptr(pw.blogit), pw.n_letters, N, ptr(lp), st)
+        return lp[slot]
+
+    # -----------------------------------------------------------------------------------------------------------
+    def _forward_train(self, x, S, mask, chain_mask_all, residue_idx, chain_encoding_all, batch, decoding_order):
+        """The forward of protein_mpnn.py:450-515 under autograd, on the dense model's training kernels
+        (mpnn_amd.training: saved pre-activations, hand-written backward, weight gradients, deterministic sums).  The
+        edge list maps onto them exactly as in `_forward`: node mask 1, slot validity as the edge weight
+        (mpnn_message_train with w_valid for the decoder), the column blocks of out_v.0 / out_e.0 taken as views of
+        the parameters so that their gradients land on the reference-shaped tensors."""
+        import types
+
+        from . import training as T
+
+        dev = x.device
+        p_drop = float(self.encoder_layers[0].dropout1.p if len(self.encoder_layers) else
+                       (self.decoder_layers[0].dropout1.p if len(self.decoder_layers) else 0.0)) if self.training else 0.0
+        eps = float(self.augment_eps) if self.training else 0.0
+        B, L, slot, scatter, Xd, maskd, ridx, chain, Sd, maskf = self._dense_inputs(
+            x, S, mask, chain_mask_all, residue_idx, chain_encoding_all, batch, noise_eps=eps)
+        N = B * L
+        T._ZEROS.reset(dev)
+        self.__dict__.pop("_packed", None)   # an optimizer step follows: the inference kernels' packed weights go stale
+        check_weight_range(self)
+        with torch.no_grad():
+            atoms, E32, E64, valid, K = self._graph(Xd, maskd, B, L)
+            ones = torch.ones(N, device=dev, dtype=torch.float32)
+            g = T.Graph(E64, E32, ones, valid, K)
+            degree = valid.sum(-1).reshape(N).contiguous()
+        A = 6 if self.use_virtual_center else 5
+        # parameters in the kernels' conventions, as differentiable views / permutations (see _Packed)
+        emb = self.embedding.emb.weight
+        Wpos = torch.cat([emb[:65].flip(0), emb[65:66]]).t()             # table[d][p] = Wpos[p][d]
+        bpos = torch.zeros(emb.shape[1], device=dev, dtype=torch.float32)
+        pidx = torch.arange(A * A, device=dev)
+        src_block = (pidx % A) * A + (pidx // A)
+        rbf_cols = (src_block[:, None] * 16 + torch.arange(16, device=dev)[None, :]).reshape(-1)
+        cols = torch.cat([A * A * 16 + torch.arange(16, device=dev), rbf_cols])   # [positional | RBF] as FeaturesFn packs
+        W0 = self.edge_mlp[0].weight[:, cols]
+        slot_e = T.GradSlot()
+        hE = T.FeaturesFn.apply(g, slot_e, atoms, ridx, chain, A, Wpos, bpos, W0, self.edge_mlp[1].weight,
+                                self.edge_mlp[1].bias, self.edge_mlp[2].weight, self.edge_mlp[2].bias,
+                                self.edge_mlp[0].bias)
+        hV = torch.zeros(N, H, device=dev, dtype=torch.float32)
+        has_occ = self.occupancy_cutoff is not None
+        if has_occ:
+            with torch.no_grad():
+                occ = torch.empty(N, device=dev, dtype=torch.float32)
+                call("mpnn_occupancy", ptr(atoms), ptr(maskd), B, L, float(self.occupancy_cutoff), ptr(occ), stream_ptr())
+            hV = hV + self.occupancy_mlp(occ.view(N, 1))
+
+        enc, dec = list(self.encoder_layers), list(self.decoder_layers)
+
+        def view(lyr):   # the attribute names training._node_update reads (the dense model's)
+            return types.SimpleNamespace(W3=lyr.out_v[4], norm1=lyr.norm1, norm2=lyr.norm2, scale=lyr.scale,
+                                         dense=types.SimpleNamespace(W_in=lyr.dense.out[0], W_out=lyr.dense.out[2]))
+
+        Wv = {id(l_): l_.out_v[0].weight.split(H, dim=1) for l_ in enc + dec}
+        We = {id(l_): l_.out_e[0].weight.split(H, dim=1) for l_ in enc}
+
+        def msg_blocks(lyr):        # out_v.0 on [x_i | x_j | e] (:151): P = W[:, :H] x_i + b, Q = W[:, H:2H] x_j
+            return [(Wv[id(lyr)][0], lyr.out_v[0].bias), (Wv[id(lyr)][1], None)]
+
+        def dec_blocks(lyr):        # out_v.0 on [x_i | x_j | e | label_j] (:212-216): Pa, and the neighbour term
+            return [(Wv[id(lyr)][0], lyr.out_v[0].bias), (Wv[id(lyr)][1], None)]
+
+        first = msg_blocks(enc[0]) if enc else (dec_blocks(dec[0]) if dec else [])
+        if enc and not has_occ:     # h_V = 0: P is the bias row, Q is zero
+            proj = [enc[0].out_v[0].bias.float().expand(N, H), torch.zeros(N, H, device=dev, dtype=torch.float32)]
+        else:
+            proj = [T.linear(hV, W, b) for W, b in first]
+
+        slot_cur = slot_e
+        for l, lyr in enumerate(enc):
+            gsum, cnt = T.MessageFn.apply(g, slot_cur, False, hE, proj[0], proj[1], None, Wv[id(lyr)][2],
+                                          lyr.out_v[2].weight, lyr.out_v[2].bias)
+            nxt = msg_blocks(enc[l + 1]) if l + 1 < len(enc) else (dec_blocks(dec[0]) if dec else [])
+            # out_e.0 on [x_row | x_col | e] = [neighbour | centre | e] (:140-142): centre term P', neighbour term Q'
+            upd = [(We[id(lyr)][1], lyr.out_e[0].bias), (We[id(lyr)][0], None)]
+            hV, proj = T._node_update(view(lyr), hV, gsum, cnt, ones, p_drop, upd + nxt)
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
+            out_slot = T.GradSlot()
+            hE = T.EdgeUpdateFn.apply(g, slot_cur, out_slot, p_drop, seed, hE, proj[0], proj[1], We[id(lyr)][2],
+                                      lyr.out_e[2].weight, lyr.out_e[2].bias, lyr.out_e[4].weight, lyr.out_e[4].bias,
+                                      lyr.norm3.weight, lyr.norm3.bias)
+            slot_cur = out_slot
+            proj = proj[2:]
+
+        if dec:
+            with torch.no_grad():
+                order = self._decoding_order(decoding_order, scatter, chain_mask_all, maskf, B, L, dev)
+                rank = torch.zeros(N, device=dev, dtype=torch.int32)
+                call("mpnn_order_rank", ptr(order), B, L, ptr(rank), stream_ptr())
+                g.set_order(rank)
+            n_vocab = self.label_embedding.weight.shape[0]
+            onehot = torch.nn.functional.one_hot(Sd, 32 * ((n_vocab + 31) // 32)).to(torch.float32)
+            for l, lyr in enumerate(dec):
+                Pa, Bv = proj[0], proj[1]
+                # both branches of Decoder.message read the neighbour's current features; the label term is added
+                # where the neighbour is decoded earlier (:212-214)
+                TL = T.linear(self.label_embedding.weight, Wv[id(lyr)][3])
+                Arow = Bv + T.TableRowsFn.apply(TL, Sd, onehot)
+                gsum, _ = T.MessageFn.apply(g, slot_cur, "valid", hE, Pa, Arow, Bv, Wv[id(lyr)][2], lyr.out_v[2].weight,
+                                            lyr.out_v[2].bias)
+                nxt = dec_blocks(dec[l + 1]) if l + 1 < len(dec) else []
+                hV, proj = T._node_update(view(lyr), hV, gsum, degree, ones, p_drop, nxt)
+        lp = T.HeadFn.apply(hV, self.output.weight, self.output.bias)
         return lp[slot]

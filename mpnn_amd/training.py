@@ -293,6 +293,10 @@ class MessageFn(torch.autograd.Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, g, slot, dec, hE, P, RowA, RowB, W1b, W2, b2):
+        # dec: False (encoder), True (decoder), "valid" (decoder whose neighbour sum runs over edge_mask = 1 only: the
+        # edge-list model, mpnn_amd.sparse)
+        w_valid = 1 if dec == "valid" else 0
+        dec = bool(dec)
         dev = hE.device
         P, RowA = P.contiguous(), RowA.contiguous()
         RowB = RowB.contiguous() if RowB is not None else None
@@ -304,8 +308,8 @@ class MessageFn(torch.autograd.Function):
         w1p, w2p = _pack_blocks([(W1b, False), (W2, False)])  # named: a temporary's block could be reused before the launch
         call("mpnn_message_train", int(dec), ptr(hE), ptr(P), ptr(RowA), ptr(RowB), ptr(g.rank) if dec else None,
              ptr(g.E_idx32), ptr(g.mask), ptr(g.edge_mask), ptr(w1p), ptr(w2p), ptr(b2c),
-             g.B, g.L, g.K, ptr(gsum), ptr(cnt), ptr(a1), ptr(a2), stream_ptr())
-        ctx.g, ctx.dec, ctx.slot = g, dec, slot
+             g.B, g.L, g.K, ptr(gsum), ptr(cnt), ptr(a1), ptr(a2), w_valid, stream_ptr())
+        ctx.g, ctx.dec, ctx.slot, ctx.w_valid = g, dec, slot, w_valid
         ctx.save_for_backward(hE, a1, a2, W1b, W2)
         if dec:
             cnt = torch.full((g.N,), float(g.K), device=dev, dtype=torch.float32)
@@ -331,7 +335,7 @@ class MessageFn(torch.autograd.Function):
         amax = _zeros(dev, 2)
         call("mpnn_message_bwd", int(dec), ptr(dgsum), ptr(a1), ptr(a2), ptr(g.E_idx32), ptr(g.mask), ptr(g.edge_mask),
              ptr(w2t), ptr(w1t), g.B, g.L, g.K, ptr(da2), ptr(rows),
-             ptr(dP), ptr(dE), 0 if first else 1, ptr(amax), stream_ptr())
+             ptr(dP), ptr(dE), 0 if first else 1, ptr(amax), ctx.w_valid, stream_ptr())
         dRowA, dRowB = _gather(rows, g, g.sel if dec else None)
         dW2, db2 = _wgrad(da2, False, amax[0:1], a1, True, g, True)
         dW1b, _ = _wgrad(rows, True, amax[1:2], hE, False, g, False)
@@ -409,7 +413,8 @@ class FeaturesFn(torch.autograd.Function):
 
     @staticmethod
     @custom_fwd(device_type="cuda")
-    def forward(ctx, g, out_slot, atoms, residue_idx, chain_labels, n_atoms, Wpos, bpos, Wemb, lnw, lnb, We, be):
+    def forward(ctx, g, out_slot, atoms, residue_idx, chain_labels, n_atoms, Wpos, bpos, Wemb, lnw, lnb, We, be,
+                bemb=None):
         dev = atoms.device
         st = stream_ptr()
         table = torch.empty(66 * 16, device=dev, dtype=torch.float32)
@@ -424,10 +429,11 @@ class FeaturesFn(torch.autograd.Function):
         vec = [t.detach().contiguous() for t in (lnw, lnb, be)]
         hE = torch.empty(g.frag_numel(), device=dev, dtype=torch.float32)
         E0, E = torch.empty_like(hE), torch.empty_like(hE)
+        bemb_c = bemb.detach().float().contiguous() if bemb is not None else None
         call("mpnn_edge_features_train", ptr(atoms), ptr(g.E_idx32), ptr(residue_idx), ptr(chain_labels), ptr(table),
-             ptr(mu), ptr(Wemb_p), ptr(vec[0]), ptr(vec[1]), ptr(We_p), ptr(vec[2]), g.B, g.L, g.K, n_atoms, ptr(E0),
-             ptr(E), ptr(hE), st)
-        ctx.g, ctx.n_atoms, ctx.out_slot = g, n_atoms, out_slot
+             ptr(mu), ptr(Wemb_p), ptr(bemb_c), ptr(vec[0]), ptr(vec[1]), ptr(We_p), ptr(vec[2]), g.B, g.L, g.K, n_atoms,
+             ptr(E0), ptr(E), ptr(hE), st)
+        ctx.g, ctx.n_atoms, ctx.out_slot, ctx.has_bemb = g, n_atoms, out_slot, bemb is not None
         ctx.save_for_backward(atoms, residue_idx, chain_labels, table, mu, E0, E, Wemb, lnw, We)
         return hE
 
@@ -454,15 +460,18 @@ class FeaturesFn(torch.autograd.Function):
         call("mpnn_feature_chunks", ptr(atoms), ptr(g.E_idx32), ptr(residue_idx), ptr(chain_labels), ptr(mu), g.B, g.L,
              g.K, na, ptr(chunks), st)
         n = g.frag_numel()
-        dF = torch.cat([_wgrad(dE0, False, amax[1:2], chunks[c * n:(c + 1) * n], False, g, False)[0]
-                        for c in range(nch)], dim=1)                       # [128, nch*128]: d / d(raw feature)
+        parts = [_wgrad(dE0, False, amax[1:2], chunks[c * n:(c + 1) * n], False, g, ctx.has_bemb and c == 0)
+                 for c in range(nch)]
+        dF = torch.cat([p_[0] for p_ in parts], dim=1)                      # [128, nch*128]: d / d(raw feature)
+        dbemb = parts[0][1]                                                 # column sums of dE0 (None without the bias)
         G = dF[:, nrbf:nrbf + 66]                                           # sum of dE0 rows per position bucket
         W = Wemb.detach()
         npos = W.shape[1] - nrbf
         # two 128 x 66 x 16 contractions as broadcast products + ATen tree sums (a library GEMM launch each otherwise)
         dT = (G.unsqueeze(2) * W[:, :npos].unsqueeze(1)).sum(0)             # gradient of the 66 x 16 embedding table
         dWemb = torch.cat([(G.unsqueeze(2) * table.view(1, 66, 16)).sum(1), dF[:, :nrbf]], dim=1)
-        return (None, None, None, None, None, None, dT.t().contiguous(), dT.sum(0), dWemb, dln[:H], dln[H:], dWe, dbe)
+        return (None, None, None, None, None, None, dT.t().contiguous(), dT.sum(0), dWemb, dln[:H], dln[H:], dWe, dbe,
+                dbemb)
 
 
 def _node_wgrad(dy, x, want_bias):

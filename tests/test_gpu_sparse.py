@@ -8,6 +8,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _inference_unless_asked():
+    """The tests here exercise the INFERENCE kernels unless they open torch.enable_grad() themselves (with grad mode on
+    the module takes its differentiable path, as any nn.Module does)."""
+    with torch.no_grad():
+        yield
+
+
 def randomized(model, seed):
     """Every parameter away from its initial value (biases and LayerNorm vectors are otherwise 0 / 1)."""
     g = torch.Generator().manual_seed(seed)
@@ -62,13 +70,88 @@ def test_sparse_forward_matches_oracle(name):
         ref = so.forward(sd, oracle_cfg(kw), **b, decoding_order=order)
     model = model.to("cuda")
     g = {k: v.to("cuda") for k, v in b.items()}
-    out = model(**g, decoding_order=order.to("cuda"))
-    assert out.shape == ref.shape
-    err = (out.cpu().double() - ref.double()).abs()
-    tol = 1e-5 + 1e-4 * ref.double().abs()
-    worst = int((err - tol).max(-1).values.argmax())
-    assert bool((err <= tol).all()), (f"{name}: max |d log p| {float(err.max()):.3e} at node {worst} "
-                                      f"(mask {float(b['mask'][worst])}, graph {int(b['batch'][worst])})")
+    with torch.no_grad():                                  # the inference kernels
+        out = model(**g, decoding_order=order.to("cuda"))
+    with torch.enable_grad():                              # grad mode on: the differentiable path (training kernels)
+        out_grad = model(**g, decoding_order=order.to("cuda"))
+    assert not out.requires_grad and out_grad.requires_grad
+    for what, o in (("inference", out), ("differentiable", out_grad.detach())):
+        assert o.shape == ref.shape
+        err = (o.cpu().double() - ref.double()).abs()
+        tol = 1e-5 + 1e-4 * ref.double().abs()
+        worst = int((err - tol).max(-1).values.argmax())
+        assert bool((err <= tol).all()), (f"{name} ({what}): max |d log p| {float(err.max()):.3e} at node {worst} "
+                                          f"(mask {float(b['mask'][worst])}, graph {int(b['batch'][worst])})")
+
+
+@pytest.mark.parametrize("name", ["knn30_ragged", "knn48_vc_occ", "radius9", "knn16_dec_only", "knn64_tiles"])
+def test_sparse_gradients_vs_oracle_autograd(name):
+    """Training of the edge-list model (protein_mpnn.py:450-515 under autograd): a masked NLL loss and EVERY parameter
+    gradient of the HIP path against autograd through oracle/sparse_oracle.py, at the dense model's bar (1e-3 relative
+    L2 per tensor; parity unpinned as the oracle's header says).  Dropout and backbone noise off (they cannot share
+    torch's random stream)."""
+    from mpnn_amd.sparse import ProteinMPNN
+    from mpnn_amd.synthetic import synthetic_flat_batch
+    from oracle import sparse_oracle as so
+
+    kw, bkw = CASES[name]
+    torch.manual_seed(1)
+    model = randomized(ProteinMPNN(dropout=0.0, augment_eps=0.0, **kw), seed=2).train()
+    b = synthetic_flat_batch(**bkw)
+    order = b.pop("decoding_order")
+    w = b["mask"] * b["chain_mask_all"]
+
+    def loss_of(lp, S, w_):
+        return -(lp.gather(-1, S.unsqueeze(-1)).squeeze(-1) * w_).sum() / 2000.0
+
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    with torch.enable_grad():
+        ref_loss = loss_of(so.forward(sd, oracle_cfg(kw), **b, decoding_order=order), b["chain_seq_label"], w)
+        ref_loss.backward()
+    want = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items() if v.requires_grad}
+
+    model = model.to("cuda")
+    g = {k: v.to("cuda") for k, v in b.items()}
+    with torch.enable_grad():
+        lp = model(**g, decoding_order=order.to("cuda"))
+        loss = loss_of(lp, g["chain_seq_label"], w.to("cuda"))
+        loss.backward()
+    assert abs(loss.item() - ref_loss.item()) <= 1e-5 * abs(ref_loss.item()), (loss.item(), ref_loss.item())
+    total = sum(float(v.double().norm() ** 2) for v in want.values()) ** 0.5
+    bad = []
+    for n_, p_ in model.named_parameters():
+        got = p_.grad.detach().cpu().double() if p_.grad is not None else torch.zeros_like(want[n_]).double()
+        err, ref = float((got - want[n_].double()).norm()), float(want[n_].double().norm())
+        if err > 1e-3 * ref + 1e-6 * total:
+            bad.append(f"{n_}: err {err:.3e} vs norm {ref:.3e}")
+    assert not bad, "; ".join(bad[:8])
+
+
+def test_sparse_training_steps_reduce_loss():
+    """A few AdamW steps in training mode with the reference's defaults (dropout 0.1, backbone noise 0.2,
+    protein_mpnn.py:136-144, :198-200, :461-462) on the in-tree optimizer: finite, decreasing loss."""
+    from mpnn_amd import training
+    from mpnn_amd.sparse import ProteinMPNN
+    from mpnn_amd.synthetic import synthetic_flat_batch
+
+    torch.manual_seed(0)
+    model = ProteinMPNN(num_neighbors=30).train().to("cuda")
+    b = {k: v.to("cuda") for k, v in synthetic_flat_batch([96, 70, 64], seed=21, n_chains=2, unresolved_every=17).items()}
+    order = b.pop("decoding_order")
+    opt, _ = training.make_optimizer(model, lr=1e-3, max_grad_norm=1.0)
+    w = b["mask"] * b["chain_mask_all"]
+    losses = []
+    for _ in range(8):
+        opt.zero_grad(set_to_none=True)
+        with torch.enable_grad():
+            lp = model(**b, decoding_order=order)
+            _, loss = training.loss_smoothed(b["chain_seq_label"], lp, w)
+            loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(l == l and abs(l) < 1e6 for l in losses), losses
+    assert min(losses[-2:]) < losses[0], losses
+    assert all(torch.isfinite(p).all() for p in model.parameters())
 
 
 def test_sparse_random_order_checkpoint_round_trip_and_guards():
@@ -94,8 +177,8 @@ def test_sparse_random_order_checkpoint_round_trip_and_guards():
     assert not torch.equal(a1, a3)
     with pytest.raises(ValueError):
         model(**b, decoding_order=order[:, :-1])
-    with pytest.raises(RuntimeError, match="inference only"):
-        model.train()(**b)
+    with pytest.raises(RuntimeError, match="grad mode"):
+        model.train()(**b)   # training mode (dropout, noise) lives on the differentiable path only
 
 
 def test_sparse_radius_degree_limit_is_loud():
