@@ -235,22 +235,40 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
     batch = (b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
     steps, warm = max(3, min(a.steps, 10)), 2
 
+    ar_events = []
+
     def step():
-        return training.train_step(model, opt, batch, world_size=world)
+        return training.train_step(model, opt, batch, world_size=world, allreduce_timings=ar_events)
 
     for _ in range(warm):
         step()
         log("train: warm-up step done")
     quiesce_gc()
     barrier()
+    del ar_events[:]
     t0 = time.perf_counter()
     for _ in range(steps):
         loss, _ = step()
     enqueue = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0          # this rank's own steps, before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
+    ranks = None
     if dist is not None:
         elapsed = max_over_ranks(elapsed, dev, dist)
+        # what a lost percent of scaling would be made of, per rank: its own step time (the barrier aside), its host
+        # enqueue time, the gradient all-reduce (HIP events around the collective, div included)
+        ar_ms = sum(e0.elapsed_time(e1) for e0, e1 in ar_events) / max(len(ar_events), 1)
+        mine = torch.tensor([own / steps * 1e3, enqueue / steps * 1e3, ar_ms], dtype=torch.float64,
+                            device=dev if dist.get_backend() == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        ranks = {"per_rank_ms_per_step": [round(float(t[0]), 3) for t in every],
+                 "per_rank_host_enqueue_ms_per_step": [round(float(t[1]), 3) for t in every],
+                 "per_rank_allreduce_ms_per_step": [round(float(t[2]), 3) for t in every],
+                 "allreduce_ms_per_step": round(max(float(t[2]) for t in every), 3),
+                 "allreduce_bytes": 4 * sum(p.numel() for p in model.parameters())}
     assert torch.isfinite(loss)
     prof = {}
     _lib.set_profiler(prof)
@@ -266,7 +284,8 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
     frag = 8 * ((K + 15) // 16) * 1024
     step_bytes = 170 * frag * B * L
     tbps = step_bytes / (elapsed / steps) / 1e12
-    return {"metric": "residues/sec (train step: fwd + bwd + AdamW) at L=512,k=48",
+    return {**(ranks or {}),
+            "metric": "residues/sec (train step: fwd + bwd + AdamW) at L=512,k=48",
             "value": round(B * L * world * steps / elapsed, 1), "unit": "residues/s", "n_gpus": world, "steps": steps,
             "warmup": warm, "ms_per_step": round(elapsed / steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(enqueue / steps * 1e3, 3), "scaling": "weak",
@@ -281,7 +300,10 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
             "final_loss": round(float(loss), 6),
             "hip_kernels_ms_per_step": kern, "hip_kernels_total_ms": round(hip_ms, 3),
             "note": "forward, backward and weight gradients of the featurizer, edge and node stages, the output head, "
-                    "the smoothed loss and the AdamW update are HIP kernels; the sequence-embedding lookup is an ATen op"}
+                    "the smoothed loss, the sequence-term table and the AdamW update are HIP kernels (no library GEMM on "
+                    "the path); what is left to ATen is glue: index_select of the 21-row table, one_hot(S), cat / zero "
+                    "fills / copies of autograd, the decoding order's argsort; every sum is order-fixed (no "
+                    "floating-point atomics): two runs give identical gradients"}
 
 
 def assembly_leg(a, dev, with_cpu):
@@ -361,11 +383,57 @@ def sampling_leg(a, dev, rank, world, dist, barrier):
             dist.all_gather(gathered, mine_S)
             assert torch.equal(gathered[rank], mine_S)
     assert int(out["S"].min()) >= 0 and torch.isfinite(out["log_probs"]).all()
-    return {"metric": "sampled residues/sec (autoregressive, random order, virtual centre) at L=512,k=48",
-            "value": round(total * L * iters / elapsed, 1), "unit": "residues/s", "n_gpus": world, "steps": iters,
-            "ms_per_step": round(elapsed / iters * 1e3, 3), "scaling": "strong",
-            "config": {"workload": f"BASELINE configs[4]: 1 structure x L={L}, k={K}, {total} samples "
-                                   f"({mine} on rank 0), temperature 0.1", "dependency_levels": out["n_levels"]}}
+    res = {"metric": "sampled residues/sec (autoregressive, random order, virtual centre) at L=512,k=48",
+           "value": round(total * L * iters / elapsed, 1), "unit": "residues/s", "n_gpus": world, "steps": iters,
+           "ms_per_step": round(elapsed / iters * 1e3, 3), "scaling": "strong",
+           "config": {"workload": f"BASELINE configs[4]: 1 structure x L={L}, k={K}, {total} samples "
+                                  f"({mine} on rank 0), temperature 0.1", "dependency_levels": out["n_levels"]}}
+    if rank == 0:
+        from mpnn_amd import _lib
+        n_dec = len(model.decoder_layers)
+
+        def timed(n, reps=3):
+            """(wall ms per call, device ms of the decoder's level loop per call, levels) for n samples."""
+            model.sample(*args, n_samples=n, temperature=0.1, seed=7)
+            torch.cuda.synchronize()
+            prof = {}
+            t0_ = time.perf_counter()
+            for i in range(reps):
+                o = model.sample(*args, n_samples=n, temperature=0.1, seed=8 + i)
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0_) / reps * 1e3
+            _lib.set_profiler(prof)
+            o = model.sample(*args, n_samples=n, temperature=0.1, seed=8)
+            torch.cuda.synchronize()
+            _lib.set_profiler(None)
+            run = [e0.elapsed_time(e1) for name, evs in prof.items() if name.startswith("mpnn_decode_run")
+                   for e0, e1 in evs]
+            return wall, (sum(run) if run else None), o["n_levels"]
+
+        # the decoder is a chain of dependent launches (levels x decoder layers): its bound is their latency, not HBM or
+        # the matrix pipe.  achieved = device time of the level loop; the model = levels x layers x the time of ONE
+        # dependent launch at that level size (measured here: loop time / launches)
+        wall64, loop64, lv64 = timed(max(mine, 1))
+        wall8, loop8, lv8 = timed(8)
+        wall1, loop1, lv1 = timed(1)
+        if loop64 is not None:
+            res["roofline"] = {
+                "bound": "latency", "unit": "us per dependent launch",
+                "levels": lv64, "dependent_launches": lv64 * n_dec,
+                "achieved": round(loop64 * 1e3 / (lv64 * n_dec), 2),
+                "floor": round(loop1 * 1e3 / (lv1 * n_dec), 2),
+                "frac": round((loop1 / (lv1 * n_dec)) / (loop64 / (lv64 * n_dec)), 4),
+                "level_loop_ms": round(loop64, 3), "call_ms": round(wall64, 3),
+                "note": "floor = the same launch at ONE sample (a level of ~7 residues: one workgroup per residue, nothing "
+                        "to share): what a level costs when only its chain of dependent loads, weight streams (0.8 MB "
+                        "per workgroup from L2) and barriers is left; host enqueue is not on the critical path "
+                        "(mpnn_decode_run issues the whole loop from C)"}
+        res["samples_per_rank_8"] = {"ms_per_call": round(wall8, 3), "level_loop_ms": round(loop8, 3) if loop8 else None,
+                                     "levels": lv8, "sampled_residues_per_s": round(8 * L / wall8 * 1e3, 1),
+                                     "note": "what each GPU of BASELINE configs[4] (64 samples over 8 GPUs) sees"}
+        res["one_sequence"] = {"ms_per_call": round(wall1, 3), "level_loop_ms": round(loop1, 3) if loop1 else None,
+                               "levels": lv1}
+    return res
 
 
 def self_launch(n, json_fd):

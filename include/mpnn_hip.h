@@ -54,14 +54,17 @@ int mpnn_pack_linear_split(const float* W, int out_f, int in_f, int ld, int col0
 /* Element-wise probe of the device arithmetic every MLP on the path is built from (used by the unit tests):
  * mode 0: y = GELU(x), the exact-erf form of nn.GELU() (:70, :115, :149) as the kernels evaluate it
  *         (relu(x) - |x| 2^(-Q(|x|)), Q a degree-6 polynomial; within 3e-7 absolute of the fp64 erf form);
- * mode 1: y = hi + lo of the f16 hi/lo operand split that feeds the MFMAs (|x - y| <= 2^-21 |x| for 6e-5 < |x| < 65504). */
+ * mode 1: y = hi + lo of the f16 hi/lo operand split that feeds the MFMAs (|x - y| <= 2^-21 |x| for 6e-5 < |x| < 65504);
+ * mode 2: y = the single f16 rounding of the *_f16 entry points' operands (round to nearest even, +-inf from
+ *         |x| >= 65520 on: the reduced-precision mode overflows loudly too). */
 int mpnn_probe_elementwise(const float* x, int n, int mode, float* y, void* stream);
 
 /* OPERAND RANGE of every entry point that takes "packed" weights or hE_frag (all edge / node / featurizer kernels):
  * products run on the f16 matrix pipe, each fp32 operand split as f16 hi + f16 lo.  hi is a truncating conversion
  * (saturates at 65504), lo = f16(x - hi) overflows to +-inf once |x| >= 131008, so an activation or weight beyond that
- * turns the outputs into inf / NaN - never into a silently wrong finite number (fp32-class entry points; the *_f16
- * twins drop lo and SATURATE silently at 65504).  Below 6e-5 an operand keeps 3e-8 ABSOLUTE resolution (f16
+ * turns the outputs into inf / NaN - never into a silently wrong finite number.  The *_f16 twins drop lo and round hi
+ * to nearest even with gfx950's v_cvt_pk_f16_f32, which overflows to +-inf from |x| >= 65520 on: they fail the same
+ * loud way (round 2 truncated with v_cvt_pkrtz there, which saturates at 65504 - silently).  Below 6e-5 an operand keeps 3e-8 ABSOLUTE resolution (f16
  * subnormals), i.e. fewer than 22 significant bits.  mpnn_range_flag is the cheap device-side check the Python
  * wrapper uses: weights at pack time against 65504, log_probs after a forward against +inf.
  *   *flag |= bit if any x[i] is NaN or |x[i]| >= limit (limit = INFINITY: finiteness only).  No reference counterpart. */

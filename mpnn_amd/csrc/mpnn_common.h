@@ -231,25 +231,25 @@ struct BFrag {
 // states only for instructions it can see).
 typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// f16-products mode: ONE rounding per operand, by gfx950's packed round-to-nearest-even conversion.  Unlike
+// v_cvt_pkrtz (which truncates and therefore SATURATES at 65504) it overflows to +-inf from |x| >= 65520 on, so an
+// out-of-range activation poisons the log-probs and trips the wrapper's finiteness check exactly as in the fp32-class
+// path - the reduced-precision mode cannot return silently wrong finite numbers either.
+__device__ __forceinline__ unsigned cvt_pk_f16_rne(float lo_half, float hi_half) {
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo_half), "v"(hi_half));
+  return r;
+}
+
 __device__ __forceinline__ void split_pair(const f32x4 a, const f32x4 b, BFrag& o) {
-#if defined(MPNN_FAST) || defined(MPNN_SPLIT_CVT)
   const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  u32x4 hi, lo;
+#if defined(MPNN_FAST)
+  u32x4 hi;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const fp16x2_t hp = __builtin_amdgcn_cvt_pkrtz(v[2 * j], v[2 * j + 1]);
-    hi[j] = __builtin_bit_cast(unsigned, hp);
-#ifndef MPNN_FAST  // round-1 form: convert hi back, subtract, convert again (3 instructions per element)
-    const fp16x2_t lp = __builtin_amdgcn_cvt_pkrtz(v[2 * j] - (float)hp[0], v[2 * j + 1] - (float)hp[1]);
-    lo[j] = __builtin_bit_cast(unsigned, lp);
-#endif
-  }
+  for (int j = 0; j < 4; ++j) hi[j] = cvt_pk_f16_rne(v[2 * j], v[2 * j + 1]);
+  asm("s_nop 1" : "+v"(hi));  // (asm results feed MFMAs: the wait states hipcc cannot see, as below)
   o.hi = __builtin_bit_cast(h8, hi);
-#ifndef MPNN_FAST
-  o.lo = __builtin_bit_cast(h8, lo);
-#endif
 #else
-  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   u32x4 hi, lo;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {

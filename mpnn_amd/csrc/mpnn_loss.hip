@@ -143,6 +143,7 @@ k_sum_ordered(const float* __restrict__ part, int n, float* __restrict__ out) {
 // element-wise probes of the two device helpers every MLP on the path is built from (unit tests of the arithmetic):
 //   mode 0: y = gelu(x)          (mpnn_common.h; reference nn.GELU(), :70, :115, :149)
 //   mode 1: y = hi + lo of the f16 hi/lo split the matrix-pipe kernels feed their MFMAs with (x must be |x| < 65504)
+//   mode 2: y = the ONE f16 rounding of the f16-products mode (round to nearest even; +-inf from |x| >= 65520 on)
 __global__ void k_probe(const float* __restrict__ x, int n, int mode, float* __restrict__ y) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int i8 = i * 8;
@@ -153,6 +154,14 @@ __global__ void k_probe(const float* __restrict__ x, int n, int mode, float* __r
   if (mode == 0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = gelu(v[j]);
+  } else if (mode == 2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned p = cvt_pk_f16_rne(v[2 * j], v[2 * j + 1]);
+      const fp16x2_t h = __builtin_bit_cast(fp16x2_t, p);
+      v[2 * j] = (float)h[0];
+      v[2 * j + 1] = (float)h[1];
+    }
   } else {
     BFrag b;
     split_pair(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, b);
@@ -343,7 +352,7 @@ extern "C" int mpnn_range_flag(const float* x, long long n, float limit, int32_t
 }
 
 extern "C" int mpnn_probe_elementwise(const float* x, int n, int mode, float* y, void* stream) {
-  MPNN_CHECK_ARG(x && y && n > 0 && (mode == 0 || mode == 1), "mpnn_probe_elementwise: bad arguments");
+  MPNN_CHECK_ARG(x && y && n > 0 && mode >= 0 && mode <= 2, "mpnn_probe_elementwise: bad arguments");
   hipLaunchKernelGGL(k_probe, dim3((n + 2047) / 2048), dim3(256), 0, (hipStream_t)stream, x, n, mode, y);
   MPNN_LAUNCH_CHECK();
 }

@@ -35,33 +35,76 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allreduce_gradients(params, world: int, group=None):
-    """Average `.grad` over ranks with a single flat all-reduce (parameters without a grad count as zeros)."""
+class FlatGradients:
+    """One flat fp32 buffer that holds every parameter's gradient, in parameter order.  After `reduce()` each
+    `p.grad` IS a view of it (no copy back), so the optimizer that follows - the in-tree multi-tensor AdamW takes the
+    views' pointers - steps on the buffer the collective left its result in.  The buffer is kept between steps (the
+    6.6 MB are allocated once); `timings` receives one (start, end) HIP-event pair per collective when given."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = None
+
+    def _buffer(self, like):
+        if self.flat is None or self.flat.device != like.device or self.flat.dtype != like.dtype:
+            self.flat = torch.empty(self.numel, device=like.device, dtype=like.dtype)
+        return self.flat
+
+    def reduce(self, world: int, group=None, timings=None):
+        if not self.params:
+            return
+        flat = self._buffer(self.params[0])
+        views, off = [], 0
+        for p in self.params:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        # gather: ONE multi-tensor copy of the gradients autograd produced (separate tensors) into the flat buffer;
+        # a parameter whose gradient already is the view (nothing re-allocated it) costs nothing
+        src, dst = [], []
+        for p, v in zip(self.params, views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        ev = None
+        if timings is not None and flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        if flat.is_cuda and dist.get_backend(group) == "gloo":  # CPU rehearsal backend: stage through host memory
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(world)
+        if ev is not None:
+            ev[1].record()
+            timings.append(ev)
+        for p, v in zip(self.params, views):
+            p.grad = v          # re-point: the optimizer reads the reduced values in place
+
+
+_FLAT = {}
+
+
+def allreduce_gradients(params, world: int, group=None, timings=None):
+    """Average `.grad` over ranks with a single flat all-reduce (parameters without a grad count as zeros); afterwards
+    every `.grad` is a view of the flat buffer (FlatGradients)."""
     params = [p for p in params if p.requires_grad]
     # MPNN_FORCE_ALLREDUCE=1: a one-rank process group still takes the collective path (rehearsal of the RCCL path on a 1-GPU box)
     forced = os.environ.get("MPNN_FORCE_ALLREDUCE") == "1" and dist.is_initialized()
     if (world <= 1 and not forced) or not params:
         return
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-    if flat.is_cuda and dist.get_backend(group) == "gloo":  # CPU rehearsal backend: stage through host memory
-        host = flat.cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-        flat.copy_(host)
-    else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    flat.div_(world)
-    off, dst, src = 0, [], []
-    for p in params:
-        n = p.numel()
-        g = flat[off:off + n].view_as(p)
-        if p.grad is None:
-            p.grad = g.clone()
-        else:
-            dst.append(p.grad)
-            src.append(g)
-        off += n
-    if dst:
-        torch._foreach_copy_(dst, src)  # one multi-tensor launch instead of one copy per parameter
+    key = tuple(id(p) for p in params)
+    fg = _FLAT.get(key)
+    if fg is None:
+        _FLAT.clear()          # one model at a time: do not pin the buffers of models that are gone
+        fg = _FLAT[key] = FlatGradients(params)
+    fg.reduce(world, group, timings)
 
 
 def broadcast_parameters(params, src: int = 0, group=None):

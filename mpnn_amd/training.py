@@ -790,7 +790,7 @@ def make_optimizer(model, lr=1e-3, weight_decay=1e-2, total_steps=None, max_grad
 
 
 def train_step(model, optimizer, batch, world_size=1, fix_order=None, fix_backbone_noise=None, scheduler=None,
-               max_grad_norm=None):
+               max_grad_norm=None, allreduce_timings=None):
     """One optimisation step (reference train.py:376-395): forward, smoothed loss, backward, (gradient all-reduce),
     optional gradient-norm clipping (:389-390), optimizer and scheduler step.  max_grad_norm: None keeps what the
     in-tree optimizer was built with (no clipping for other optimizers); a number sets it for this and later steps,
@@ -802,7 +802,8 @@ def train_step(model, optimizer, batch, world_size=1, fix_order=None, fix_backbo
     mask_for_loss = mask * chain_M
     _, loss = loss_smoothed_fused(S, log_probs, mask_for_loss)
     loss.backward()
-    distributed.allreduce_gradients(model.parameters(), world_size)  # no-op for a single rank
+    # no-op for a single rank; allreduce_timings (a list) receives one HIP-event pair around the collective
+    distributed.allreduce_gradients(model.parameters(), world_size, timings=allreduce_timings)
     from . import optim
     if isinstance(optimizer, optim.AdamW):
         if max_grad_norm is not None:

@@ -32,6 +32,18 @@ def _worker(rank, world, port, out):
     loss.backward()
     distributed.allreduce_gradients(params, world)
     flat = torch.cat([p.grad.reshape(-1) for p in params])
+    # every gradient is now a view of ONE flat buffer (no copy back), in parameter order
+    base = params[0].grad.untyped_storage().data_ptr()
+    assert all(p.grad.untyped_storage().data_ptr() == base for p in params)
+    assert params[1].grad.data_ptr() == params[0].grad.data_ptr() + 4 * params[0].numel()
+    # a second step: fresh gradients from autograd, same buffer, same averages
+    for p in params:
+        p.grad = None
+    loss = lin(x).sum() + (extra.sum() if rank == 0 else 0.0)
+    loss.backward()
+    distributed.allreduce_gradients(params, world)
+    assert params[0].grad.untyped_storage().data_ptr() == base
+    assert torch.equal(torch.cat([p.grad.reshape(-1) for p in params]), flat)
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     gw = [torch.empty_like(w0) for _ in range(world)]

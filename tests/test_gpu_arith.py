@@ -56,3 +56,19 @@ def test_f16_split_keeps_22_bits():
     # below the f16 normal range the split keeps 2^-24 ABSOLUTE resolution (documented in mpnn_common.h)
     t = torch.rand(100_000, generator=g) * 2.0 ** -14
     assert float((probe(t, 1) - t).abs().max()) <= 2.0 ** -25 + 1e-12
+
+
+def test_f16_mode_rounding_is_nearest_even_and_overflows_to_inf():
+    """The *_f16 entry points' single operand rounding (mode 2: gfx950's v_cvt_pk_f16_f32): equal to torch's fp32 ->
+    fp16 cast (round to nearest even), including +-inf from |x| >= 65520 on - an out-of-range operand poisons the
+    result instead of saturating at 65504."""
+    g = torch.Generator().manual_seed(2)
+    x = torch.cat([torch.randn(1_000_000, generator=g) * 100.0, torch.randn(100_000, generator=g) * 1e-4,
+                   torch.tensor([65503.9, 65504.0, 65519.9, 65520.0, 7e4, -65519.9, -65520.0, -1e9, 0.0, -0.0,
+                                 2049.0, 2051.0, 1e-8])])
+    if x.numel() % 8:
+        x = torch.cat([x, torch.zeros(8 - x.numel() % 8)])
+    y = probe(x, 2)
+    want = x.to(torch.float16).float()
+    assert torch.equal(y, want), (y[-16:], want[-16:])
+    assert torch.isinf(y[x.abs() >= 65520.0]).all() and torch.isfinite(y[x.abs() < 65520.0]).all()

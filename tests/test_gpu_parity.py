@@ -272,7 +272,10 @@ def test_f16_product_mode_tolerance(shape):
     assert agree >= 0.99
 
 
-def test_f16_product_mode_against_the_oracle():
+@pytest.mark.parametrize("shape", [dict(B=2, L=384, seed=41, lengths=[384, 300], n_chains=3),
+                                   dict(B=1, L=4096, seed=43, n_chains=5),       # BASELINE configs[3]'s shape
+                                   dict(B=4, L=512, seed=42, n_chains=2)])
+def test_f16_product_mode_against_the_oracle(shape):
     """The reduced-precision forward held against the ORACLE (the reference's fp32 arithmetic), not only against this
     repo's fp32-class path: same bar (max |d log_prob| <= 5e-2, argmax agreement >= 99 %); neighbour lists and causal
     masks stay bit-exact because the search and the masks run the exact kernels in either mode."""
@@ -280,7 +283,7 @@ def test_f16_product_mode_against_the_oracle():
 
     kw = dict(k_neighbors=48)
     model = build_model(kw)
-    b = synthetic_batch(B=2, L=384, seed=41, lengths=[384, 300], n_chains=3, design_fraction=0.6)
+    b = synthetic_batch(design_fraction=0.6, **shape)
     rec = {n: v.numpy() for n, v in b.items()}
     ref = run_oracle(model, kw, rec)
     model.set_precision("f16")

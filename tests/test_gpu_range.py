@@ -121,3 +121,17 @@ def test_sparse_model_has_check_numerics():
     from mpnn_amd import sparse
 
     assert callable(getattr(sparse.ProteinMPNN, "check_numerics", None))
+
+
+def test_f16_mode_overflows_loudly_too():
+    """The reduced-precision mode rounds each operand ONCE, to nearest even, with an instruction that overflows to inf
+    (round 2 truncated with v_cvt_pkrtz, which saturates at 65504 and so returned finite, wrong numbers): the same
+    overflowing model is reported by check_numerics() in f16 mode."""
+    model = _overflowing_model()
+    model.set_precision("f16")
+    rec = _batch()
+    out = run_hip(model, rec, keep=False)
+    model.set_precision("fp32")
+    assert not bool(torch.isfinite(out).all())
+    with pytest.raises(RuntimeError, match="inf / NaN"):
+        model.check_numerics()
