@@ -33,11 +33,19 @@ int mpnn_version(void);
 
 /* Recommended workspace size in bytes for the entry points that take one ("mpnn_edge_wgrad": n_rows = residues;
  * "mpnn_node_wgrad" / "mpnn_node_wgrad_batch": n_rows = rows of the operands, n_blocks = number of 128 x 128 blocks of
- * all outputs of the call).  Smaller workspaces are accepted down to one partial (16512 floats) and cost parallelism.
+ * all outputs of the call; smaller workspaces are accepted down to one partial (16512 floats) and cost parallelism).
+ * The backward / loss / norm entry points that reduce per-workgroup partial sums in a fixed order need theirs in full:
+ * "mpnn_enc_edge_update_bwd", "mpnn_edge_features_bwd" (fixed), "mpnn_node_update_bwd", "mpnn_logits_log_softmax_bwd",
+ * "mpnn_loss_smoothed" (n_rows = residues), "mpnn_gather_rows" (n_blocks = max_chunks), "mpnn_grad_sumsq" (n_rows =
+ * elements of the largest tensor, n_blocks = tensors).
  * 0 for the entry points that need none, -1 for an unknown name.  Host-only: touches no device.
  * (SURVEY section 8b lists this query in the build-defined ABI; nothing in the reference corresponds to it.) */
 long long mpnn_workspace_bytes(const char* entry, int n_rows, int n_blocks);
 const char* mpnn_last_error(void);
+/* 1 when the library was built with one of the timing-only ablation switches of csrc/mpnn_ablation.h (its results are
+ * wrong by design; the Python binding refuses such a build unless MPNN_ALLOW_ABLATION=1), else 0.  No reference
+ * counterpart: build hygiene. */
+int mpnn_ablation_build(void);
 
 /* nn.Linear weight W[out_f, ld] columns [col0, col0+in_f) -> packed[ceil(out/16)][ceil(in/16)][64][4],
  * zero padded.  Weight layout prep for every Linear on the path (:64-69, :112-114, :147-148, :212, :400, :412). */
@@ -163,17 +171,12 @@ int mpnn_dec_message_valid(const float* hE_frag, const float* PQ, int ldpq, int 
                            const float* W1b_packed, const float* W2_packed, const float* b2, int B, int L, int K,
                            float* gsum, void* stream);
 
-/* One dependency level of the autoregressive sampler in ONE launch: every listed residue goes through all decoder
- * layers (mpnn_dec_layer_subset's arithmetic, layer after layer inside the workgroup that owns the residue) and the
- * sampling head (mpnn_sample_subset's arithmetic: log-probs, tempered draw, sequence term folded into every layer's A
- * rows).  Valid because a residue of a level reads only residues of earlier levels and its own rows.  No reference
- * counterpart (the reference has no sampler).  layers[l] describes decoder layer l:
+/* One decoder layer of the sampler's level loop, as mpnn_decode_run takes it (HOST struct):
  *   P / RowA (ld, off): the layer's Pa | A rows, per sample row; offEnc: column of its encoder rows in PVenc;
  *   hV_in -> hV_out; PQ [.., nproj * 128]: the NEXT layer's Pa | A rows (nproj = 0 for the last layer);
  *   layers[l].hV_in must be layers[l-1].hV_out and layers[l].P / RowA must live in layers[l-1].PQ.
- * mpnn_decode_level runs layers first_layer .. n_layers-1 and the head (first_layer = 0: the whole level; the layers
- * before first_layer must then have been run by mpnn_dec_layer_subset on the same list).
- * K <= 48, 1..4 layers, n_letters <= 32. */
+ * (Round 2 also had mpnn_decode_level, a whole level in one launch; it measured slower than the per-layer launches -
+ * profiles/r02_sampler_levels.txt - and was removed in round 3.) */
 typedef struct mpnn_level_layer {
   const float* P; int ldp, offP;
   float* RowA; int lda, offA;      /* written too: the drawn letter's term is folded into the A rows */
@@ -185,24 +188,6 @@ typedef struct mpnn_level_layer {
   const float *Wproj_packed, *bproj; int nproj;
   float* hV_out; float* PQ;
 } mpnn_level_layer;
-/* Validates the layer table and uploads its device form to plan_dev (MPNN_DECODE_PLAN_BYTES of device memory owned by
- * the caller; stream-ordered copy): once per sampling call, before the first mpnn_decode_level that uses it. */
-#define MPNN_DECODE_PLAN_BYTES 1024
-int mpnn_decode_plan(const mpnn_level_layer* layers, int n_layers, void* plan_dev, void* stream);
-int mpnn_decode_plan_f16(const mpnn_level_layer* layers, int n_layers, void* plan_dev, void* stream);
-int mpnn_decode_level(const float* hE_frag, const float* PVenc, int ldenc, const int32_t* rank, const int32_t* E_idx32,
-                      const float* mask, const float* edge_mask, const int32_t* node_list, int n_list, int enc_nodes,
-                      int L, int K, float cnt_const, const void* plan_dev, int first_layer, int n_layers,
-                      const float* Wlogit_packed,
-                      const float* logit_b, const float* logit_bias, int n_letters, float temperature, uint64_t seed,
-                      const float* designable, const int64_t* S_in, int64_t* S_out, float* log_probs, const float* TS,
-                      int ld_ts, void* stream);
-int mpnn_decode_level_f16(const float* hE_frag, const float* PVenc, int ldenc, const int32_t* rank,
-                          const int32_t* E_idx32, const float* mask, const float* edge_mask, const int32_t* node_list,
-                          int n_list, int enc_nodes, int L, int K, float cnt_const, const void* plan_dev,
-                          int first_layer, int n_layers, const float* Wlogit_packed, const float* logit_b, const float* logit_bias, int n_letters,
-                          float temperature, uint64_t seed, const float* designable, const int64_t* S_in,
-                          int64_t* S_out, float* log_probs, const float* TS, int ld_ts, void* stream);
 
 /* Node update shared by EncLayer / DecLayer (:81-88, :127-137, FFN :151-155) followed by the next kernels'
  * node projections:  dh = (W3 gsum + cnt b3) / scale;  x = LN1(h + dh);  h' = mask LN2(x + FFN(x));
@@ -511,7 +496,7 @@ int mpnn_sample_subset(const float* hV, const float* Wout_packed, const float* b
  * for all layers followed by mpnn_sample_subset (draw_fused = 0) - the same launches, in the same order, with the same
  * results as those per-level calls, issued from C instead of ~4 ctypes calls per level (the host side of a Python
  * loop over ~70 levels x 3 launches was 3 of the 7.7 ms of a 64 x 512 sampling call).  `layers` is a HOST array of
- * n_layers mpnn_level_layer (as for mpnn_decode_plan; layers[n_layers-1].nproj must be 0); the A rows the draw folds
+ * n_layers mpnn_level_layer (layers[n_layers-1].nproj must be 0); the A rows the draw folds
  * the sequence term into are layers[l].RowA / lda / offA.  Returns at the first failing launch.  K <= 48.
  * No reference counterpart (the reference has no sampler). */
 int mpnn_decode_run(const float* hE_frag, const float* PVenc, int ldenc, const int32_t* rank, const int32_t* E_idx32,

@@ -23,7 +23,7 @@ _U64 = ctypes.c_uint64
 
 
 class LevelLayer(ctypes.Structure):
-    """mpnn_level_layer (include/mpnn_hip.h): one decoder layer of mpnn_decode_level."""
+    """mpnn_level_layer (include/mpnn_hip.h): one decoder layer of mpnn_decode_run."""
     _fields_ = [("P", _P), ("ldp", _I), ("offP", _I), ("RowA", _P), ("lda", _I), ("offA", _I), ("offEnc", _I),
                 ("W1b_packed", _P), ("W2_packed", _P), ("b2", _P), ("hV_in", _P),
                 ("W3_packed", _P), ("b3", _P), ("ln1_w", _P), ("ln1_b", _P), ("Win_packed", _P), ("b_in", _P),
@@ -50,9 +50,6 @@ SIGNATURES = {
     "mpnn_dec_message": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "mpnn_dec_message_valid": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "mpnn_dec_message_shared": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
-    "mpnn_decode_plan": [ctypes.POINTER(LevelLayer), _I, _P, _P],
-    "mpnn_decode_level": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P, _P,
-                          _I, _F, _U64, _P, _P, _P, _P, _P, _I, _P],
     "mpnn_decode_run": [_P, _P, _I, _P, _P, _P, _P, _P, ctypes.POINTER(_I), _I, _I, _I, _I, _F,
                         ctypes.POINTER(LevelLayer), _I, _P, _P, _P, _I, _F, _U64, _P, _P, _P, _P, _P, _I, _I, _P],
     "mpnn_node_update": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _I,
@@ -105,7 +102,7 @@ SIGNATURES = {
 F16_ENTRIES = ("mpnn_edge_features", "mpnn_enc_message", "mpnn_enc_edge_update", "mpnn_dec_message", "mpnn_node_update",
                "mpnn_dec_message_subset", "mpnn_node_update_subset", "mpnn_dec_message_shared", "mpnn_dec_layer_subset", "mpnn_dec_layer_sample_subset",
                "mpnn_linear_rows", "mpnn_edge_features_biased", "mpnn_dec_message_valid",
-               "mpnn_decode_level", "mpnn_decode_plan", "mpnn_decode_run")
+               "mpnn_decode_run")
 for _n in F16_ENTRIES:
     SIGNATURES[_n + "_f16"] = SIGNATURES[_n]
 
@@ -157,6 +154,12 @@ def load() -> ctypes.CDLL:
     lib.mpnn_workspace_bytes.argtypes = [ctypes.c_char_p, _I, _I]
     lib.mpnn_last_error.restype = ctypes.c_char_p
     lib.mpnn_last_error.argtypes = []
+    lib.mpnn_ablation_build.restype = _I
+    lib.mpnn_ablation_build.argtypes = []
+    if lib.mpnn_ablation_build() and os.environ.get("MPNN_ALLOW_ABLATION") != "1":
+        raise RuntimeError(f"{LIB_PATH} was built with a timing-only ablation switch (csrc/mpnn_ablation.h): its results "
+                           "are wrong by design.  Rebuild with plain `make`, or set MPNN_ALLOW_ABLATION=1 for an A/B "
+                           "timing run")
     _lib = lib
     return lib
 

@@ -28,6 +28,20 @@ extern "C" long long mpnn_workspace_bytes(const char* entry, int n_rows, int n_b
     if (chunks < 1) chunks = 1;
     return chunks * (n_blocks > 0 ? n_blocks : 1) * part;
   }
+  // per-workgroup partial sums that a second small launch adds in a fixed order (no floating-point atomics)
+  const long long f = (long long)sizeof(float);
+  if (!strcmp(entry, "mpnn_enc_edge_update_bwd") || !strcmp(entry, "mpnn_edge_features_bwd"))
+    return 1024 * 256 * f;  // 256 floats per workgroup, one workgroup per CU at most
+  if (!strcmp(entry, "mpnn_node_update_bwd")) return ((n_rows + 63) / 64) * 640LL * f;
+  if (!strcmp(entry, "mpnn_logits_log_softmax_bwd")) return ((n_rows + 63) / 64) * 4128LL * f;
+  if (!strcmp(entry, "mpnn_loss_smoothed")) return ((n_rows + 255) / 256 + 1) * f;
+  if (!strcmp(entry, "mpnn_gather_rows")) return (n_blocks > 0 ? n_blocks : 1) * 256LL * f;  // n_blocks = max_chunks
+  if (!strcmp(entry, "mpnn_grad_sumsq"))  // n_rows = the largest tensor's elements, n_blocks = tensors
+    return ((n_rows + 2047) / 2048) * (long long)(n_blocks > 0 ? n_blocks : 1) * f;
   if (!strncmp(entry, "mpnn_", 5)) return 0;  // every other entry point works in the caller's inputs and outputs only
   return -1;
 }
+
+// 1 when the library was built with a timing-only ablation switch (mpnn_ablation.h): its outputs are wrong by design
+#include "mpnn_ablation.h"
+extern "C" int mpnn_ablation_build(void) { return MPNN_ABLATION_BUILD; }

@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mpnn_ablation.h"
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MPNN_H 128          // hidden size the kernels are specialised for
@@ -60,23 +62,7 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // 10 VALU instructions, ONE transcendental, no division:  min, 6 fma, exp2, max, fma  (|x| and the negations are
 // free source modifiers).  The clamp at 12 only keeps the polynomial (negative leading coefficient) out of the region
 // where it would turn over; Phi(-12) ~ 1.8e-33 is already 0 in the result.
-// MPNN_GELU_AS selects the round-1 form (Abramowitz-Stegun 7.1.26 erfc: rcp + exp2 + 12 plain ops, 3.3e-7).
-#ifdef MPNN_GELU_AS
-__device__ __forceinline__ float gelu(float x) {
-  const float z = x * 0.70710678118654752440f;
-  const float az = fabsf(z);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  p *= t;
-  const float zs = z * 1.20112240878644977f;          // sqrt(log2 e): exp(-z^2) = exp2(-(zs^2))
-  const float e = __builtin_amdgcn_exp2f(-(zs * zs));
-  const float r = (0.5f * fabsf(x)) * (p * e);         // 0.5 |x| erfc(|z|)  >= 0
-  return fmaxf(x, 0.f) - r;                           // x Phi(x) = relu(x) - 0.5 |x| erfc(|x| / sqrt 2)
-}
-#else
+// (Round 1 used the Abramowitz-Stegun 7.1.26 erfc: rcp + exp2 + 12 plain ops, 3.3e-7.)
 __device__ __forceinline__ float gelu(float x) {
   // min / max through v_med3_f32: fminf / fmaxf make hipcc canonicalise their inputs first (one more v_max each)
   const float ax = fabsf(x);
@@ -88,9 +74,6 @@ __device__ __forceinline__ float gelu(float x) {
   q = fmaf(q, a, 1.151201725e+00f);
   q = fmaf(q, a, 9.999930859e-01f);
   const float e = __builtin_amdgcn_exp2f(-q);          // Phi(-|x|)
-#ifdef MPNN_GELU_NOASM
-  return fmaf(-ax, e, __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()));
-#else
   // relu(x) - |x| e as exactly two instructions.  Left to hipcc this tail costs four issue slots per element: the
   // relu becomes a canonicalising v_max pair, and the SLP vectoriser fuses two elements' FMAs into one v_pk_fma_f32,
   // which has no |x| modifier (one v_or per element to build -|x|) and occupies the issue port ~10 cycles next to
@@ -100,9 +83,7 @@ __device__ __forceinline__ float gelu(float x) {
   float r, o;
   asm("v_max_f32 %0, 0, %2\n\tv_fma_f32 %1, -|%2|, %3, %0" : "=&v"(r), "=v"(o) : "v"(x), "v"(e));
   return o;
-#endif
 }
-#endif
 
 __device__ __forceinline__ f32x4 gelu4(f32x4 v) {
 #ifdef MPNN_ABL_NOGELU  // timing-only ablation build: never shipped
@@ -154,9 +135,6 @@ __device__ __forceinline__ float column_sum(float v) {
 // behind the VALU write of its source); the leading s_nop covers the producer of the first operand.
 __device__ __forceinline__ f32x4 column_sum4(f32x4 v) {
 #if defined(MPNN_ABL_NOREDUCE)
-  return v;
-#elif defined(MPNN_DPP_NOASM)
-  v.x = column_sum(v.x); v.y = column_sum(v.y); v.z = column_sum(v.z); v.w = column_sum(v.w);
   return v;
 #else
   float a = v.x, b = v.y, c = v.z, d = v.w;
@@ -384,17 +362,6 @@ __device__ __forceinline__ void split_kstep_stream(WRing<D>& r, WP Wlane, int kk
 #endif
 #pragma unroll
     for (int c = 0; c < KT; ++c) Y[to][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, B[c].hi, Y[to][c], 0, 0, 0);
-#ifdef MPNN_SCHED_PIN
-    // pin the order hipcc would otherwise undo (it sinks the ring's reads next to their first use): this step's
-    // fragment reads first, then its MFMAs, whose operands were read D steps earlier
-#ifndef MPNN_FAST
-    if (q + D < NKK * NTO) __builtin_amdgcn_sched_group_barrier(0x120, 2, 0);  // 2 memory reads (VMEM 0x020 | DS 0x100)
-    __builtin_amdgcn_sched_group_barrier(0x008, 3 * KT, 0);
-#else
-    if (q + D < NKK * NTO) __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, KT, 0);
-#endif
-#endif
   }
 }
 

@@ -51,69 +51,18 @@ static void stamp_report(const char* what, int base) {
 
 MPNN_KERNELS_BEGIN
 
-#ifndef MPNN_MSG_WAVES
-#define MPNN_MSG_WAVES 8
-#endif
-// 1: always use the tile-wise message kernel; 0: one-residue-per-wave kernel for K <= 48, tile-wise above
-// (measured equal at K = 48: 0.26 ms per launch at B32 x L512 either way)
-#ifndef MPNN_MSG_TILEWISE
-#define MPNN_MSG_TILEWISE 0
-#endif
-#ifndef MPNN_UPD_WAVES
-#define MPNN_UPD_WAVES 8
-#endif
-// 1: the message kernel issues the next residue's 24 row gathers and its first hE k-step as two bursts (round-2 form);
-// 0: spread over the row tiles of the reduction
-#ifndef MPNN_MSG_BURST
-#define MPNN_MSG_BURST 0
-#endif
-#ifndef MPNN_L1_PIN
-#define MPNN_L1_PIN 2
-#endif
-// tuning switches of the edge update's epilogue (A/B builds): where the next residue's first hE k-step (X0) and its
-// gathered rows (ROWS) are issued.  X0: 0 = at the loop top, 1 = after the LayerNorm statistics (before the stores).
-// ROWS: 0 = right after layer 3, 1 = after the LayerNorm statistics.
-// LDS weight fragments are read MPNN_LDS_RING (to, kk) steps ahead of the MFMAs that use them (0: read and wait
-// in place, which is what hipcc schedules on its own at this register pressure: ~64 exposed LDS latencies per layer)
-#ifndef MPNN_LDS_RING
-#define MPNN_LDS_RING 0
-#endif
-// Waves w and w + 4 of an 8-wave workgroup share a SIMD and run the same program: started together they stay in
-// lockstep - both in their MFMA phase (sharing the matrix pipe), then both in their GELU phase (the matrix pipe idle);
-// measured: kernel time = MFMA time + VALU time.  Delaying waves 4-7 once, by about half a phase, puts one wave's MFMAs
-// beside the other's VALU work for the rest of the kernel.  Unit: s_sleep ticks of 64 cycles; 0 = off.
-#ifndef MPNN_STAGGER
-#define MPNN_STAGGER 0
-#endif
-#ifndef MPNN_UPD_X0
-#define MPNN_UPD_X0 0
-#endif
-#ifndef MPNN_UPD_X0_T
-#define MPNN_UPD_X0_T 2
-#endif
-#ifndef MPNN_UPD_ROWS
-#define MPNN_UPD_ROWS 2
-#endif
-#ifndef MPNN_UPD_W3_FLAT
-#define MPNN_UPD_W3_FLAT 0  // 1: W13's streamed halves by flat_load (round-2 form)
-#endif
-#ifndef MPNN_UPD_RES_SPREAD
-#define MPNN_UPD_RES_SPREAD 1
-#endif
-// layer 1 touches every cache line of its residue's later hE k-steps with one-dword loads at its start (no registers
-// held: a software prefetch into L2), so the real loads a k-step later find the lines on their way
-#ifndef MPNN_X0_FIRST
+// Tuning constants of the shipped kernels.  The variants that were measured against them and rejected (tile-wise
+// kernels at K <= 48, burst prefetches, an LDS fragment read-ahead ring, staggered half-workgroups, other placements
+// of the next residue's loads, flat W13 streams) were deleted in round 3; their numbers are in profiles/r02_ab_*.txt
+// and their code in the history before that commit.  The only compile-time forks left are MPNN_FAST (the f16-product
+// twin), MPNN_STAMP (phase stamps) and the timing-only MPNN_ABL_* ablations listed in mpnn_ablation.h.
+#define MPNN_MSG_WAVES 8   // waves per workgroup of the message kernel (two per SIMD)
+#define MPNN_UPD_WAVES 8   // ... of the edge update
+// where, within the message kernel's first layer, the residue's own P row is requested: k-step MPNN_X0_FIRST of
+// MPNN_X0_SPAN (the other k-step buffer is dead there)
 #define MPNN_X0_FIRST 2
-#endif
-#ifndef MPNN_X0_SPAN
 #define MPNN_X0_SPAN 2
-#endif
-#ifndef MPNN_X_PREFETCH
-#define MPNN_X_PREFETCH 0
-#endif
-#ifndef MPNN_UPD_RING
 #define MPNN_UPD_RING 4  // W13 lo fragments in flight ahead of their MFMAs (edge update, layer 3; 7 -> 4: 26 -> 6 spilled registers, -2 %)
-#endif
 
 // layer 1 of every edge MLP: acc += W1b * hE[node]; hE feature tiles stream from HBM one k-step
 // (two tiles) ahead of their MFMAs and are split to f16 hi/lo on the fly
@@ -146,28 +95,8 @@ __device__ __forceinline__ void layer1_stream(const h8* Ws, const f32x4* __restr
   for (int u = 0; u < 2; ++u)
 #pragma unroll
     for (int c = 0; c < KT; ++c) xb[0][u][c] = x0[u][c];
-#if MPNN_LDS_RING
-  WRing<MPNN_LDS_RING> ring;
-  wring_prologue<NKK, MPNN_NT, MPNN_LDS_RING>(ring, Ws + lane);
-#endif
-#if MPNN_X_PREFETCH
-  constexpr int PF_LINES = (MPNN_NT - 2) * KT * 8;  // 128-byte lines of k-steps 1 .. NKK-1 (a tile row is 1 KiB)
-  constexpr int PF_N = (PF_LINES + 63) / 64;
-  float pf[PF_N];
-  {
-    const float* base = reinterpret_cast<const float*>(x - lane) + 2 * KT * 256;
-#pragma unroll
-    for (int i = 0; i < PF_N; ++i) {
-      const int line = 64 * i + lane;
-      pf[i] = 0.f;
-      if (line < PF_LINES) pf[i] = __builtin_nontemporal_load(base + line * 32);
-    }
-  }
-  FENCE();
-#endif
 #pragma unroll
   for (int kk = 0; kk < NKK; ++kk) {
-#if MPNN_L1_PIN == 2
     // the next k-step's 2 KT tiles, one load per output tile of this k-step (pinned: hipcc otherwise places them all
     // near the END of the k-step, a few MFMAs before the next k-step waits for them)
     if (kk + 1 == NKK) last();
@@ -178,38 +107,14 @@ __device__ __forceinline__ void layer1_stream(const h8* Ws, const f32x4* __restr
     split_kstep_hook<KT, NKK, MPNN_NT>(Ws, kk, lane, b, acc, [&](int to) {
       if (kk + 1 < NKK && to < 2 * KT) xb[(kk + 1) & 1][to / KT][to % KT] = x[((2 * (kk + 1) + to / KT) * KT + to % KT) * 64];
     });
-#else
-    if (kk + 1 < NKK) load_kstep<KT>(x, kk + 1, xb[(kk + 1) & 1]);
-    else last();
-#if MPNN_L1_PIN
-    FENCE();  // hipcc otherwise sinks these loads to the END of the k-step (fewer live registers), a few MFMAs before
-              // the next k-step waits for them
-#endif
-    BFrag b[KT];
-#pragma unroll
-    for (int c = 0; c < KT; ++c) split_pair(xb[kk & 1][0][c], xb[kk & 1][1][c], b[c]);
-#if MPNN_LDS_RING
-    split_kstep_stream<KT, NKK, MPNN_NT, MPNN_LDS_RING>(ring, Ws + lane, kk, b, acc);
-#else
-    split_kstep<KT, NKK, 0, MPNN_NT>(Ws, kk, lane, b, acc);
-#endif
-#endif
     FENCE();
   }
-#if MPNN_X_PREFETCH
-#pragma unroll
-  for (int i = 0; i < PF_N; ++i) asm volatile("" ::"v"(pf[i]));
-#endif
 }
 
-// Y += W X with W's fragments in LDS, read MPNN_LDS_RING steps ahead
+// Y += W X with W's fragments in LDS
 template <int KT>
 __device__ __forceinline__ void lds_gemm(const h8* Ws, int lane, const BFrag (&B)[NKK][KT], f32x4 (&Y)[MPNN_NT][KT]) {
-#if MPNN_LDS_RING
-  split_gemm_stream<KT, NKK, MPNN_NT, MPNN_LDS_RING>(Ws + lane, B, Y);
-#else
   split_gemm<KT, NKK, 0, MPNN_NT>(Ws, lane, B, Y);
-#endif
 }
 
 template <int KT, typename Hook = NoHook>
@@ -269,7 +174,6 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
   const int stride = rr.stride, Nend = rr.end;
   int node = rr.first;
   if (node >= Nend) return;
-  if (MPNN_STAGGER && __builtin_amdgcn_readfirstlane(wave) >= MPNN_MSG_WAVES / 2) __builtin_amdgcn_s_sleep(MPNN_STAGGER);
 
   // per-edge scalars of a residue: gathered row, scale s (dec), reduction weight w
   // shared-structure decoding (DEC, enc_mod < N): rows of the batch beyond the first enc_mod residues are further
@@ -373,24 +277,8 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
     // GELU + reduction below, not as one burst: 30 back-to-back loads (16 rows each) fill the address unit's queue and
     // the wave then waits at the ISSUE of the later ones (measured with MPNN_STAMP: 12 % of the kernel); the k-step
     // starts once half of y has been reduced (registers)
-#if MPNN_MSG_BURST
-    if (SAVE) {
-      f32x4* o = sv2 + (size_t)node * (MPNN_NT * KT * 64) + lane;
-#pragma unroll
-      for (int t = 0; t < MPNN_NT; ++t)
-#pragma unroll
-        for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(y[t][c], &o[(t * KT + c) * 64]);
-    }
-#pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t)
-#pragma unroll
-      for (int c = 0; c < KT; ++c) h1[t][c] = row_tile(rown[c], t);
-#endif
     STAMP(3);
     reduce_store<KT>(y, w, gsum + (size_t)node * MPNN_H, lane, [&](int t) {
-#if MPNN_MSG_BURST
-      if (t == MPNN_NT / 2) load_kstep<KT>(edge_block(nxt), 0, x0);
-#else
       if (SAVE) {
         f32x4* o = sv2 + (size_t)node * (MPNN_NT * KT * 64) + lane;
 #pragma unroll
@@ -412,7 +300,6 @@ k_message(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, int ldp,
 #endif
           }
       }
-#endif
     });
     STAMP(6);
     if (!DEC) {
@@ -483,7 +370,6 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
   const int stride = rr.stride, Nend = rr.end;
   int node = rr.first;
   if (node >= Nend) return;
-  if (MPNN_STAGGER && __builtin_amdgcn_readfirstlane(wave) >= MPNN_UPD_WAVES / 2) __builtin_amdgcn_s_sleep(MPNN_STAGGER);
 
   auto setup = [&](int nd, const float* (&row)[KT]) {
     const int b = nd / L;
@@ -494,10 +380,6 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 
   const float* row[KT];
   setup(node, row);
-#if MPNN_UPD_X0
-  f32x4 x0[2][KT];  // k-step 0 of the residue's hE, loaded one phase ahead
-  load_kstep<KT>(hE + (size_t)node * (MPNN_NT * KT * 64) + lane, 0, x0);
-#endif
   f32x4 h2[MPNN_NT][KT];  // carries the next residue's gathered Q' rows across iterations
 #pragma unroll
   for (int t = 0; t < MPNN_NT; ++t)
@@ -509,16 +391,8 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
     const int nxt = (node + stride < Nend) ? node + stride : Nend - 1;
     STAMP(7);
     const h8* W3u = W13;
-#if MPNN_UPD_W3_FLAT
-    LAUNDER_FLAT(W3u);
-#else
     LAUNDER(W3u);
-#endif
-#if MPNN_UPD_W3_FLAT
-    const h8* W3g = W3u + lane;
-#else
     const auto W3g = GLOBAL(W3u) + lane;
-#endif
     f32x4* x = hE + (size_t)node * (MPNN_NT * KT * 64) + lane;
     f32x4 p[MPNN_NT];  // P'_i: needed only after layer 1, loaded during its last k-step
     const float* Pi = Pb + (size_t)node * ldp + offP + 4 * g;
@@ -531,11 +405,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
     for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
       for (int c = 0; c < KT; ++c) h1[t][c] = h2[t][c];
-#if MPNN_UPD_X0
-    layer1_stream<KT>(W1s, x, lane, h1, x0, load_p);
-#else
     layer1_stream<KT>(W1s, x, lane, h1, load_p);
-#endif
     STAMP(0);
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
@@ -570,14 +440,6 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
     }
     lds_gemm<KT>(W2s, lane, hb, h2);
     STAMP(2);
-#if !MPNN_UPD_RES_SPREAD
-    if (SAVE) {
-#pragma unroll
-      for (int t = 0; t < MPNN_NT; ++t)
-#pragma unroll
-        for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(h2[t][c], &sv2[soff + (t * KT + c) * 64]);
-    }
-#endif
     // W13 stream: lo halves (and the hi halves of the fragments that do not fit into LDS), D steps ahead
     constexpr int D = MPNN_UPD_RING;
     constexpr int NQ = NKK * MPNN_NT;
@@ -595,7 +457,6 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #endif
     // residual e -> layer 3's initial accumulator (loads fly under the GELU + split of h2); the training form
     // adds it after the dropout of the MLP output instead
-#if MPNN_UPD_RES_SPREAD  // six residual loads per k-step of the GELU + split loop instead of one burst of 24
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) {
 #pragma unroll
@@ -614,17 +475,6 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
       for (int c = 0; c < KT; ++c) split_pair(gelu4(h2[2 * kk][c]), gelu4(h2[2 * kk + 1][c]), hb[kk][c]);
       FENCE();
     }
-#else
-#pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t)
-#pragma unroll
-#ifdef MPNN_ABL_NORES
-      for (int c = 0; c < KT; ++c) h1[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#else
-      for (int c = 0; c < KT; ++c) h1[t][c] = SAVE ? f32x4{0.f, 0.f, 0.f, 0.f} : x[(t * KT + c) * 64];
-#endif
-    tile_to_bfrag<MPNN_NT, KT, true>(h2, hb);
-#endif
     STAMP(3);
     // ---- layer 3.  step q = kk * 8 + to
 #ifdef MPNN_ABL_W3LDS  // timing-only ablation build: never shipped
@@ -647,12 +497,6 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #endif
     STAMP(4);
     // next residue's Q' rows -> h2 (carried to the next iteration), under the LayerNorm
-#if !MPNN_UPD_ROWS
-#pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t)
-#pragma unroll
-      for (int c = 0; c < KT; ++c) h2[t][c] = row_tile(rown[c], t);
-#endif
     // training: the residual is added after the dropout; its tiles are all requested here, in one batch (layer 3's B
     // fragments are dead: registers), not one row tile at a time behind the gathers below
     f32x4 rs[SAVE ? MPNN_NT : 1][KT];
@@ -665,13 +509,8 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
     }
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
-#if MPNN_UPD_ROWS == 2  // a few gathers per row tile instead of one burst of 24 (see the message kernel)
 #pragma unroll
       for (int c = 0; c < KT; ++c) h2[t][c] = row_tile(rown[c], t);
-#if MPNN_UPD_X0 == 1
-      if (t < 2 * KT) x0[t / KT][t % KT] = hE[(size_t)nxt * (MPNN_NT * KT * 64) + lane + t * 64];
-#endif
-#endif
       const f32x4 bb = *reinterpret_cast<const f32x4*>(b13s + 16 * t + 4 * g);
 #pragma unroll
       for (int c = 0; c < KT; ++c) {
@@ -683,23 +522,12 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
           __builtin_nontemporal_store(h1[t][c], &svz[soff + (t * KT + c) * 64]);
         }
       }
-#if MPNN_UPD_ROWS == 2
       FENCE();
-#endif
     }
     // LayerNorm statistics; then the next residue's first hE k-step is issued - BEFORE this residue's stores (vector
     // memory operations complete in issue order) - and the tiles are normalised and stored one by one
     float mean[KT], rstd[KT];
     tile_layernorm_stats<KT>(h1, mean, rstd);
-#if MPNN_UPD_X0 == 1 && MPNN_UPD_ROWS != 2
-    load_kstep<KT>(hE + (size_t)nxt * (MPNN_NT * KT * 64) + lane, 0, x0);
-#endif
-#if MPNN_UPD_ROWS == 1
-#pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t)
-#pragma unroll
-      for (int c = 0; c < KT; ++c) h2[t][c] = row_tile(rown[c], t);
-#endif
     f32x4* xo = SAVE ? hE_out + soff : x;
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
@@ -714,17 +542,6 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 #endif
 #pragma unroll
       for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(h1[t][c], &xo[(t * KT + c) * 64]);
-#if MPNN_UPD_X0 == 2
-      // the next residue's first hE k-step, half of it behind each of two stored row tiles (MPNN_UPD_X0_T, + 1): the
-      // stored tiles' registers are free, so the k-step costs no extra registers, and layer 1 does not start with a
-      // whole HBM round trip
-      if (t == MPNN_UPD_X0_T || t == MPNN_UPD_X0_T + 1) {
-        const f32x4* xn = hE + (size_t)nxt * (MPNN_NT * KT * 64) + lane;
-#pragma unroll
-        for (int c = 0; c < KT; ++c) x0[t - MPNN_UPD_X0_T][c] = xn[((t - MPNN_UPD_X0_T) * KT + c) * 64];
-      }
-      FENCE();
-#endif
     }
     STAMP(5);
   }
@@ -738,9 +555,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
 // from LDS once per column tile instead of once per residue (LDS ~30 % busy, the VALU stays the bound).
 // Works for any K (loop count = ceil(K / 16)).
 // ---------------------------------------------------------------------------
-#ifndef MPNN_MSGT_WAVES
 #define MPNN_MSGT_WAVES 12
-#endif
 
 template <bool DEC>
 __global__ void __launch_bounds__(MPNN_MSGT_WAVES * 64)
@@ -1243,141 +1058,6 @@ k_dec_layer_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, 
 #endif
 }
 
-// ---------------------------------------------------------------------------
-// A whole dependency level in ONE launch: within a level a residue's decoder layers and its draw read only residues
-// of EARLIER levels (their rows were finished by earlier launches) and its own rows, so a workgroup takes its tile of
-// LV_NODES residues through every layer and then through the sampling head (mpnn_sample.h).  What a layer costs a
-// level is its chain of dependent memory operations, so everything that does not depend on the previous layer is
-// taken off that chain: the item's indices and its split hE tile are set up once; a layer's gathered neighbour rows
-// and its W3 fragments are in flight before its message weights are staged; while eight waves run a layer's node
-// phase the other four stage the NEXT layer's second message matrix into the half of LDS the exchange buffer does not
-// cover.  The tile's own P / hV rows travel between layers through global memory, ordered by workgroup barriers.
-// Replaces n_layers + 1 dependent launches per level.
-// ---------------------------------------------------------------------------
-#include "mpnn_sample.h"
-
-struct LevelLayer {  // one decoder layer of the device-side plan (mpnn_decode_plan writes it)
-  const float* P; int ldp, offP;
-  float* A; int lda, offA;
-  int offEnc;
-  const h8 *W1b, *W2; const float* b2;
-  const float* hV_in;
-  const h8* W3; const float *b3, *ln1w, *ln1b;
-  const h8* Win; const float* bin;
-  const h8* Wout; const float *bout, *ln2w, *ln2b;
-  float inv_scale;
-  const h8* Wproj; const float* bproj; int nproj;
-  float* hV_out; float* PQ;
-};
-static_assert(sizeof(LevelLayer) * 4 <= MPNN_DECODE_PLAN_BYTES, "mpnn_hip.h: MPNN_DECODE_PLAN_BYTES too small");
-// The kernel's view of the same bytes: every pointer typed as GLOBAL memory.  A pointer loaded from memory has no
-// known address space, and through the plain struct every weight stream and row read of the kernel became a
-// flat_load (229 of them), which count on lgkmcnt: each wait for an LDS read then also waited for the streams.
-#define MPNN_GP(T) const __attribute__((address_space(1))) T*
-struct LevelLayerG {
-  MPNN_GP(float) P; int ldp, offP;
-  __attribute__((address_space(1))) float* A; int lda, offA;
-  int offEnc;
-  MPNN_GP(h8) W1b; MPNN_GP(h8) W2; MPNN_GP(float) b2;
-  MPNN_GP(float) hV_in;
-  MPNN_GP(h8) W3; MPNN_GP(float) b3; MPNN_GP(float) ln1w; MPNN_GP(float) ln1b;
-  MPNN_GP(h8) Win; MPNN_GP(float) bin;
-  MPNN_GP(h8) Wout; MPNN_GP(float) bout; MPNN_GP(float) ln2w; MPNN_GP(float) ln2b;
-  float inv_scale;
-  MPNN_GP(h8) Wproj; MPNN_GP(float) bproj; int nproj;
-  __attribute__((address_space(1))) float* hV_out; __attribute__((address_space(1))) float* PQ;
-};
-static_assert(sizeof(LevelLayerG) == sizeof(LevelLayer), "LevelLayerG must mirror LevelLayer");
-
-__global__ void __launch_bounds__(MPNN_MSGT_WAVES * 64)
-k_decode_level(const f32x4* __restrict__ hE, const float* __restrict__ PVenc, int ldenc, const int* __restrict__ rank,
-               const int* __restrict__ E_idx, const float* __restrict__ mask, const float* __restrict__ edge_mask,
-               const int* __restrict__ node_list, int n_list, int enc_mod, int L, int K, int KT, float cnt_const,
-               const LevelLayerG* __restrict__ plan, int n_layers, const f32x4* __restrict__ Wlogit,
-               const float* __restrict__ blogit,
-               const float* __restrict__ logit_bias, int n_letters, float inv_temperature, unsigned long long seed,
-               const float* __restrict__ designable, const long long* __restrict__ S_in, long long* __restrict__ S_out,
-               float* __restrict__ log_probs, const float* __restrict__ TS, int ld_ts, int lvn, int first_layer) {
-  __shared__ h8 lds_base[2 * WSPLIT];
-  __shared__ float gsl_base[16][MPNN_H];
-  __shared__ float pr[16][33];
-  __shared__ int pick[16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x;
-  const int nlive = min(lvn, n_list - tile * lvn);
-  STAMP_DECL;
-#ifdef MPNN_STAMP
-  const long long rt0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz constant clock: slot 7 = shader clocks per 100 MHz tick
-#endif
-  LevelItem it;
-  STAMP(0);
-  for (int l = first_layer; l < n_layers; ++l) {
-    const LevelLayerG y = plan[l];  // uniform: scalar loads
-    // an opaque zero in every LDS address of the iteration: without it the ~100 (lane, constant) address sums of the
-    // body are hoisted out of the layer loop and live - spilled to scratch - across it
-    int zero;
-    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
-    h8* lds = lds_base + zero;
-    float (*gsl)[MPNN_H] = gsl_base + zero;
-    LdsFill f1, f2;
-    lds_fill_issue(f1, (const h8*)y.W1b);
-    if (l == first_layer) {  // later layers: W2 was staged during the previous node phase
-      lds_fill_issue(f2, (const h8*)y.W2);
-      level_item_setup(it, hE, rank, E_idx, mask, edge_mask, node_list, tile, lvn, nlive, enc_mod, L, K, KT);
-    }
-    f32x4 xt[MPNN_NT], h1[MPNN_NT][1];
-    level_rows_load(it, (float*)y.A, y.lda, y.offA, PVenc, ldenc, y.offEnc, xt, h1);
-    W3Frags w3;
-    if (wave < LV_NODE_WAVES) w3_prefetch(w3, (const h8*)y.W3);
-    lds_fill_commit(f1, lds);
-    if (l == first_layer) lds_fill_commit(f2, lds + WSPLIT);
-    for (int i = threadIdx.x; i < 16 * MPNN_H; i += blockDim.x) (&gsl[0][0])[i] = 0.f;
-    __syncthreads();
-    STAMP(1);
-    if (it.has) level_message(it, lds, lds + WSPLIT, (const float*)y.b2, (const float*)y.P, y.ldp, y.offP, xt, h1, gsl);
-    STAMP(2);
-    __syncthreads();  // neighbour sums complete; the message weights in LDS are dead from here on
-    STAMP(3);
-    if (wave >= LV_NODE_WAVES && l + 1 < n_layers) {
-      // the four waves without node work stage the next layer's W2 (upper half of lds; ex covers the lower half)
-      const h8* src = (const h8*)plan[l + 1].W2;
-      constexpr int NT = (MPNN_MSGT_WAVES - LV_NODE_WAVES) * 64;
-      const int t0 = threadIdx.x - LV_NODE_WAVES * 64;
-      for (int i0 = t0; i0 < WSPLIT; i0 += 8 * NT) {
-        h8 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[i0 + u * NT];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) lds[WSPLIT + i0 + u * NT] = v[u];
-      }
-    }
-    f32x4 hnew_unused[MPNN_NT][1];
-    level_node(lds, gsl, w3, node_list, n_list, tile, lvn, mask, (const float*)y.hV_in, cnt_const, (const float*)y.b3, (const float*)y.ln1w, (const float*)y.ln1b, (const h8*)y.Win, (const float*)y.bin,
-               (const h8*)y.Wout, (const float*)y.bout, (const float*)y.ln2w, (const float*)y.ln2b, y.inv_scale, (const h8*)y.Wproj, (const float*)y.bproj, y.nproj, (float*)y.hV_out, (float*)y.PQ, hnew_unused);
-    STAMP(4);
-    // the tile's hV / P rows written above are read by the next layer (or the head) of this workgroup, and the next
-    // layer's LDS fill overwrites the exchange buffer
-    __threadfence_block();
-    __syncthreads();
-    STAMP(5);
-  }
-  if (wave == 0) {
-    const int col = lane & 15, idx = tile * lvn + col;
-    const bool live = col < lvn && idx < n_list;
-    const int nd = node_list[live ? idx : n_list - 1];
-    sample_columns((const float*)plan[n_layers - 1].hV_out, Wlogit, blogit, logit_bias, n_letters, nd, live, inv_temperature, seed,
-                   designable, S_in, S_out, log_probs, pr, pick, lane);
-  }
-  __syncthreads();
-  fold_sequence_rows<MPNN_MSGT_WAVES, 2>([&](int l, int n) { return (float*)plan[l].A + (size_t)n * plan[l].lda + plan[l].offA; },
-                                         n_layers, TS, ld_ts, node_list + tile * lvn, nlive, pick, wave, lane);
-  STAMP(6);
-#ifdef MPNN_STAMP
-  st_acc[7] = (unsigned long long)(__builtin_amdgcn_s_memrealtime() - rt0);
-#endif
-  if (threadIdx.x < 64) STAMP_FLUSH(0);  // wave 0 takes part in every phase: its clock is the level's timeline
-}
-
 MPNN_KERNELS_END
 
 // ===========================================================================
@@ -1408,7 +1088,7 @@ extern "C" int MPNN_API(mpnn_enc_message)(const float* hE_frag, const float* PQ,
 #ifdef MPNN_STAMP
   stamp_report("message: layer1 | gelu1+split | layer2 | save | - | - | reduce + next loads | cnt+loop top", 0);
 #endif
-  if (MPNN_MSG_TILEWISE || KT > 3) {
+  if (KT > 3) {  // four column tiles: the tile-wise kernel (one 16-neighbour tile per wave)
     dim3 grid(edge_grid(N, MPNN_MSGT_WAVES)), block(MPNN_MSGT_WAVES * 64);
     hipLaunchKernelGGL((k_message_tiles<false>), grid, block, 0, (hipStream_t)stream, (const f32x4*)hE_frag, PQ, ldpq,
                        offP, PQ, ldpq, offQ, (const float*)nullptr, 0, 0, (const int*)nullptr, E_idx32, mask,
@@ -1456,7 +1136,7 @@ static int launch_dec_message(const char* who, const float* hE_frag, const float
                  "mpnn_dec_message_shared: rows must be a multiple of the structures (and K <= 48)");
   (void)who;
   const int N = B * L, KT = (K + 15) / 16;
-  if (MPNN_MSG_TILEWISE || KT > 3) {
+  if (KT > 3) {
     dim3 grid(edge_grid(N, MPNN_MSGT_WAVES)), block(MPNN_MSGT_WAVES * 64);
     hipLaunchKernelGGL((k_message_tiles<true>), grid, block, 0, (hipStream_t)stream, (const f32x4*)hE_frag, PQ, ldpq,
                        offPa, PQ, ldpq, offA, PVenc, ldenc, offEnc, rank, E_idx32, mask, edge_mask,
@@ -1501,72 +1181,6 @@ extern "C" int MPNN_API(mpnn_dec_message_shared)(const float* hE_frag, const flo
                                        int n_struct, int L, int K, float* gsum, void* stream) {
   return launch_dec_message("mpnn_dec_message_shared", hE_frag, PQ, ldpq, offPa, offA, PVenc, ldenc, offEnc, rank, E_idx32,
                             mask, edge_mask, W1b_packed, W2_packed, b2, B, n_struct, L, K, gsum, stream);
-}
-
-// Device-side plan of the one-launch-per-level decoder: the layer table is DATA the kernel reads with scalar loads
-// (a by-value kernel argument indexed by the layer would be copied to scratch).  Validated and uploaded once per
-// sampling call; plan_dev: MPNN_DECODE_PLAN_BYTES of device memory the caller owns.
-extern "C" int MPNN_API(mpnn_decode_plan)(const mpnn_level_layer* layers, int n_layers, void* plan_dev, void* stream) {
-  MPNN_CHECK_ARG(layers && plan_dev && n_layers >= 1 && n_layers <= 4, "mpnn_decode_plan: need 1..4 layers and a plan buffer");
-  LevelLayer tab[4] = {};
-  for (int l = 0; l < n_layers; ++l) {
-    const mpnn_level_layer& y = layers[l];
-    MPNN_CHECK_ARG(y.P && y.RowA && y.W1b_packed && y.W2_packed && y.b2 && y.hV_in && y.W3_packed && y.b3 && y.ln1_w &&
-                       y.ln1_b && y.Win_packed && y.b_in && y.Wout8_packed && y.b_out && y.ln2_w && y.ln2_b && y.hV_out,
-                   "mpnn_decode_plan: null pointer in a layer");
-    MPNN_CHECK_ARG(y.scale != 0.f && y.nproj >= 0 && (y.nproj == 0 || (y.Wproj_packed && y.bproj && y.PQ)) &&
-                       mult4(y.ldp, y.offP, y.lda, y.offA, y.offEnc),
-                   "mpnn_decode_plan: bad layer (strides/offsets multiples of 4 floats; projections need Wproj, bproj, PQ)");
-    // a layer's input rows must be the previous layer's outputs: the kernel orders them only within a workgroup
-    MPNN_CHECK_ARG(l == 0 || (y.hV_in == layers[l - 1].hV_out && layers[l - 1].nproj >= 2),
-                   "mpnn_decode_plan: layer l must read the hV rows (and Pa | A projections) layer l-1 writes");
-    LevelLayer& z = tab[l];
-    z.P = y.P; z.ldp = y.ldp; z.offP = y.offP;
-    z.A = y.RowA; z.lda = y.lda; z.offA = y.offA;
-    z.offEnc = y.offEnc;
-    z.W1b = (const h8*)y.W1b_packed; z.W2 = (const h8*)y.W2_packed; z.b2 = y.b2;
-    z.hV_in = y.hV_in;
-    z.W3 = (const h8*)y.W3_packed; z.b3 = y.b3; z.ln1w = y.ln1_w; z.ln1b = y.ln1_b;
-    z.Win = (const h8*)y.Win_packed; z.bin = y.b_in;
-    z.Wout = (const h8*)y.Wout8_packed; z.bout = y.b_out; z.ln2w = y.ln2_w; z.ln2b = y.ln2_b;
-    z.inv_scale = 1.0f / y.scale;
-    z.Wproj = (const h8*)y.Wproj_packed; z.bproj = y.bproj; z.nproj = y.nproj;
-    z.hV_out = y.hV_out; z.PQ = y.PQ;
-  }
-  const hipError_t e = hipMemcpyAsync(plan_dev, tab, sizeof(tab), hipMemcpyHostToDevice, (hipStream_t)stream);
-  if (e != hipSuccess) {
-    mpnn_set_error(hipGetErrorString(e));
-    return (int)e;
-  }
-  return 0;
-}
-
-// One dependency level of the sampler in one launch (k_decode_level)
-extern "C" int MPNN_API(mpnn_decode_level)(const float* hE_frag, const float* PVenc, int ldenc, const int32_t* rank,
-                                 const int32_t* E_idx32, const float* mask, const float* edge_mask,
-                                 const int32_t* node_list, int n_list, int enc_nodes, int L, int K, float cnt_const,
-                                 const void* plan_dev, int first_layer, int n_layers, const float* Wlogit_packed,
-                                 const float* logit_b, const float* logit_bias, int n_letters, float temperature,
-                                 uint64_t seed, const float* designable, const int64_t* S_in, int64_t* S_out,
-                                 float* log_probs, const float* TS, int ld_ts, void* stream) {
-  MPNN_CHECK_ARG(hE_frag && PVenc && rank && E_idx32 && mask && node_list && plan_dev && Wlogit_packed && logit_b &&
-                     designable && S_in && S_out && log_probs && TS,
-                 "mpnn_decode_level: null pointer");
-  MPNN_CHECK_ARG(n_list > 0 && L > 0 && enc_nodes > 0 && enc_nodes % L == 0 && K >= 1 && K <= 48 && n_layers >= 1 &&
-                     n_layers <= 4 && first_layer >= 0 && first_layer < n_layers && n_letters >= 1 && n_letters <= 32 &&
-                     temperature > 0.f && (ldenc & 3) == 0 && (ld_ts & 3) == 0,
-                 "mpnn_decode_level: bad sizes (K <= 48, 1..4 decoder layers, n_letters <= 32, temperature > 0)");
-  const int KT = (K + 15) / 16;
-#ifdef MPNN_STAMP
-  stamp_report("decode level: setup | rows+fill | message | wait | node | fence | head", 0);
-#endif
-  const int lvn = level_nodes_per_wg(n_list);
-  hipLaunchKernelGGL(k_decode_level, dim3(ceil_div(n_list, lvn)), dim3(MPNN_MSGT_WAVES * 64), 0, (hipStream_t)stream,
-                     (const f32x4*)hE_frag, PVenc, ldenc, rank, E_idx32, mask, edge_mask, node_list, n_list, enc_nodes, L,
-                     K, KT, cnt_const, (const LevelLayerG*)plan_dev, n_layers, (const f32x4*)Wlogit_packed, logit_b,
-                     logit_bias, n_letters, 1.0f / temperature, (unsigned long long)seed, designable,
-                     (const long long*)S_in, (long long*)S_out, log_probs, TS, ld_ts, lvn, first_layer);
-  MPNN_LAUNCH_CHECK();
 }
 
 // ---- training forward: same kernels, pre-activations saved for mpnn_edge_bwd.hip (K <= 64) ----

@@ -15,9 +15,6 @@
 #include "mpnn_bwd_common.h"
 
 #define MPNN_BWD_WAVES 8
-#ifndef MPNN_BWD_BATCH_LOADS
-#define MPNN_BWD_BATCH_LOADS 1
-#endif
 
 // y <- y * gelu'(a) with a streamed from the saved pre-activations; per-feature sums over the residue's edges
 // go to dP (the h_i projection's gradient); the (optionally s-scaled) rows are written row-major for the gather
@@ -26,7 +23,6 @@ __device__ __forceinline__ void first_layer_grad(f32x4 (&y)[MPNN_NT][KT], float 
                                                  const float (&s)[KT], float* __restrict__ dP, float* __restrict__ nat,
                                                  int lane) {
   const int g = lane >> 4, col = lane & 15;
-#if MPNN_BWD_BATCH_LOADS
   // the whole saved tensor of the residue in flight at once (the B fragments of the GEMM before are dead: registers),
   // pinned ahead of the arithmetic: tile-by-tile the wave paid one HBM round trip per row tile
   f32x4 av[MPNN_NT][KT];
@@ -35,17 +31,12 @@ __device__ __forceinline__ void first_layer_grad(f32x4 (&y)[MPNN_NT][KT], float 
 #pragma unroll
     for (int c = 0; c < KT; ++c) av[t][c] = __builtin_nontemporal_load(&a[(t * KT + c) * 64]);
   FENCE();
-#endif
 #pragma unroll
   for (int t = 0; t < MPNN_NT; ++t) {
     f32x4 ps = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
-#if MPNN_BWD_BATCH_LOADS
       y[t][c] *= gelu_grad4(av[t][c]) * unscale;
-#else
-      y[t][c] *= gelu_grad4(__builtin_nontemporal_load(&a[(t * KT + c) * 64])) * unscale;
-#endif
       ps += y[t][c];
       if (SCALE) y[t][c] *= s[c];
       __builtin_nontemporal_store(y[t][c], reinterpret_cast<f32x4*>(nat + (size_t)(16 * c + col) * MPNN_H + 16 * t + 4 * g));
@@ -100,23 +91,17 @@ k_message_bwd(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, con
     f32x4 d[MPNN_NT][KT];
     {
       const float* dg = dgsum + (size_t)node * MPNN_H + 4 * g;
-#if MPNN_BWD_BATCH_LOADS
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t)
 #pragma unroll
         for (int c = 0; c < KT; ++c) d[t][c] = __builtin_nontemporal_load(&a2[off + (t * KT + c) * 64]);
       FENCE();
-#endif
 #pragma unroll
       for (int t = 0; t < MPNN_NT; ++t) {
         const f32x4 gs = row_tile(dg, t);
 #pragma unroll
         for (int c = 0; c < KT; ++c) {
-#if MPNN_BWD_BATCH_LOADS
           d[t][c] = gelu_grad4(d[t][c]) * (gs * w[c]);
-#else
-          d[t][c] = gelu_grad4(__builtin_nontemporal_load(&a2[off + (t * KT + c) * 64])) * (gs * w[c]);
-#endif
           __builtin_nontemporal_store(d[t][c], &da2[off + (t * KT + c) * 64]);
         }
         FENCE();
@@ -132,7 +117,6 @@ k_message_bwd(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, con
     un = grad_to_bfrag<KT>(y, db, &amax_l[1]);
     zero_tile<KT>(d);
     split_gemm<KT, NKK, 0, MPNN_NT>(W1s, lane, db, d);
-#if MPNN_BWD_BATCH_LOADS
     if (accumulate) {  // uniform
       f32x4 prev[MPNN_NT][KT];
 #pragma unroll
@@ -150,16 +134,6 @@ k_message_bwd(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, con
 #pragma unroll
         for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(d[t][c] * un, &dE[off + (t * KT + c) * 64]);
     }
-#else
-#pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t)
-#pragma unroll
-      for (int c = 0; c < KT; ++c) {
-        f32x4 v = d[t][c] * un;
-        if (accumulate) v += dE[off + (t * KT + c) * 64];
-        __builtin_nontemporal_store(v, &dE[off + (t * KT + c) * 64]);
-      }
-#endif
   }
   __syncthreads();
   if (threadIdx.x < 2) atomicMax(amax + threadIdx.x, amax_l[threadIdx.x]);
@@ -175,14 +149,7 @@ k_message_bwd(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, con
 #ifndef MPNN_BWD_W1_RING
 #define MPNN_BWD_W1_RING 3
 #endif
-#ifndef MPNN_BWD_W1_GLOBAL
-#define MPNN_BWD_W1_GLOBAL 0  // 1: global_load stream (measured slower, see LAUNDER_FLAT)
-#endif
-#if MPNN_BWD_W1_GLOBAL
-#define MPNN_BWD_W1_PTR(p) GLOBAL(p)
-#else
 #define MPNN_BWD_W1_PTR(p) (p)
-#endif
 template <int KT>
 __global__ void __launch_bounds__(MPNN_BWD_WAVES * 64)
 k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __restrict__ a2,
@@ -209,11 +176,7 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
   for (int node = blockIdx.x * MPNN_BWD_WAVES + wave; node < N; node += stride) {
     LAUNDER(ln_w);
     const h8* W1u = W11bT;
-#if MPNN_BWD_W1_GLOBAL
-    LAUNDER(W1u);
-#else
     LAUNDER_FLAT(W1u);
-#endif
     const size_t off = (size_t)node * (MPNN_NT * KT * 64) + lane;
     f32x4 x[MPNN_NT][KT], d[MPNN_NT][KT];
 #pragma unroll
@@ -241,7 +204,6 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
     // ---- through W13, gelu'(a2)
     zero_tile<KT>(x);
     split_gemm<KT, NKK, 0, MPNN_NT>(W3s, lane, db, x);
-#if MPNN_BWD_BATCH_LOADS
     {
       f32x4 av[MPNN_NT][KT];  // db is dead: registers for the whole saved tensor in flight at once
 #pragma unroll
@@ -259,17 +221,6 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
         FENCE();
       }
     }
-#else
-#pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t) {
-#pragma unroll
-      for (int c = 0; c < KT; ++c) {
-        x[t][c] *= gelu_grad4(__builtin_nontemporal_load(&a2[off + (t * KT + c) * 64])) * un;
-        __builtin_nontemporal_store(x[t][c], &da2_out[off + (t * KT + c) * 64]);
-      }
-      FENCE();
-    }
-#endif
     un = grad_to_bfrag<KT>(x, db, &amax_l[1]);
     // ---- through W12, gelu'(a1)
     zero_tile<KT>(d);
@@ -283,7 +234,6 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
     // ---- de = dz (residual) + W11b^T da1 ; W11b^T streams from L2
     zero_tile<KT>(x);
     split_gemm_stream<KT, NKK, MPNN_NT, MPNN_BWD_W1_RING>(MPNN_BWD_W1_PTR(W1u) + lane, db, x);
-#if MPNN_BWD_BATCH_LOADS
     {
       const f32x4* rsrc = drop_thresh ? dE : dz_out;
       f32x4 res[MPNN_NT][KT];
@@ -297,15 +247,6 @@ k_edge_update_bwd(const f32x4* dy, const f32x4* __restrict__ z, const f32x4* __r
 #pragma unroll
         for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(x[t][c] * un + res[t][c], &dE[off + (t * KT + c) * 64]);
     }
-#else
-#pragma unroll
-    for (int t = 0; t < MPNN_NT; ++t)
-#pragma unroll
-      for (int c = 0; c < KT; ++c) {
-        const f32x4 res = drop_thresh ? dE[off + (t * KT + c) * 64] : dz_out[off + (t * KT + c) * 64];
-        __builtin_nontemporal_store(x[t][c] * un + res, &dE[off + (t * KT + c) * 64]);
-      }
-#endif
   }
   __syncthreads();
   if (threadIdx.x < 2 * MPNN_H) {
@@ -405,9 +346,6 @@ __device__ __forceinline__ f32x4 quad_transpose(f32x4 v) {
   return v;
 }
 
-#ifndef MPNN_WGRAD_SPLIT_MIX
-#define MPNN_WGRAD_SPLIT_MIX 1  // hi / lo split as in split_pair (mpnn_common.h): 1.5 instead of 4 instructions per element
-#endif
 // x -> f16 hi (truncated) + f16 lo = f16(x - hi): v_cvt_pkrtz for two hi halves, one v_fma_mix per lo half.  The values
 // come from DPP moves / loads (never straight from an MFMA) and go to LDS stores.
 __device__ __forceinline__ void split4(const f32x4 x, h4& hi, h4& lo) {
@@ -423,14 +361,7 @@ __device__ __forceinline__ void split4(const f32x4 x, h4& hi, h4& lo) {
   lo = __builtin_bit_cast(h4, (u32x2_t){l[0], l[1]});
 }
 
-#ifndef MPNN_WGRAD_NT
-#define MPNN_WGRAD_NT 1  // operand streams by non-temporal loads
-#endif
-#if MPNN_WGRAD_NT
 #define WGRAD_LOAD(p) __builtin_nontemporal_load(p)
-#else
-#define WGRAD_LOAD(p) (*(p))
-#endif
 #ifndef MPNN_WGRAD_WAVES
 #define MPNN_WGRAD_WAVES 8  // waves per workgroup: 8 (one 16-row tile of dW per wave, ~100 registers, two workgroups =
                             // 16 waves per CU) against 4 (two tiles, ~165 registers, three workgroups = 12 waves):
@@ -439,18 +370,8 @@ __device__ __forceinline__ void split4(const f32x4 x, h4& hi, h4& lo) {
 #ifndef MPNN_WGRAD_WG_PER_CU
 #define MPNN_WGRAD_WG_PER_CU (MPNN_WGRAD_WAVES == 8 ? 2 : 3)
 #endif
-#ifndef MPNN_WGRAD_EARLY_FETCH
-#define MPNN_WGRAD_EARLY_FETCH 0  // 1: next residue's tiles requested as the conversion frees their registers (no gain)
-#endif
-#ifndef MPNN_WGRAD_X32
-#define MPNN_WGRAD_X32 0  // 1: full-depth MFMA form over pairs of column tiles - fewer MFMA cycles, but 12 more registers
-                          // (two waves per SIMD, or spills at three): 3.84 / 4.67 against 3.65 ms per step, not adopted
-#endif
-#ifndef MPNN_WGRAD_CONTIG
-#define MPNN_WGRAD_CONTIG 0  // 1: a workgroup walks a contiguous range of residues instead of a grid stride
-#endif
 template <bool A_NAT, bool B_GELU, int KTM>
-__global__ void __launch_bounds__(64 * MPNN_WGRAD_WAVES, (MPNN_WGRAD_X32 && KTM <= 3) ? MPNN_WGRAD_WG_PER_CU : 1)
+__global__ void __launch_bounds__(64 * MPNN_WGRAD_WAVES)
 k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigned* __restrict__ amax, int N, int KT,
         float* __restrict__ part) {
   constexpr int WG_LDK = 16 * KTM + 4;
@@ -488,14 +409,8 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
       for (int c = 0; c < KTM; ++c)
         if (c < KT) fetch_one(node, tt, c);
   };
-#if MPNN_WGRAD_CONTIG
-  const int per = (N + gridDim.x - 1) / gridDim.x;
-  int node = blockIdx.x * per;
-  const int Nend = min(N, node + per), nstep = 1;
-#else
   int node = blockIdx.x;
   const int Nend = N, nstep = gridDim.x;
-#endif
   if (node < Nend) fetch(node);
   for (; node < Nend; node += nstep) {
 #ifdef MPNN_ABL_WGRAD_STREAM  // timing-only ablation build (never shipped): the operand streams alone
@@ -515,9 +430,6 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
       for (int c = 0; c < KTM; ++c) {
         if (c < KT) {
           f32x4 a = va[tt][c], b = vb[tt][c];
-#if MPNN_WGRAD_EARLY_FETCH
-          if (node + nstep < Nend) fetch_one(node + nstep, tt, c);  // the registers are free again: next residue's tile
-#endif
           if (B_GELU) b = gelu4(b);
           bacc[tt] += a;
           a *= sc;
@@ -526,18 +438,8 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
           a = quad_transpose(a);
           b = quad_transpose(b);
           h4 ah, al, bh, bl;
-#if MPNN_WGRAD_SPLIT_MIX
           split4(a, ah, al);
           split4(b, bh, bl);
-#else
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            ah[r] = (_Float16)a[r];
-            al[r] = (_Float16)(a[r] - (float)ah[r]);
-            bh[r] = (_Float16)b[r];
-            bl[r] = (_Float16)(b[r] - (float)bh[r]);
-          }
-#endif
           const int frow = 16 * t + 4 * g + (col & 3), ecol = 16 * c + 4 * (col >> 2);
           *reinterpret_cast<h4*>(&sA[0][frow][ecol]) = ah;
           *reinterpret_cast<h4*>(&sA[1][frow][ecol]) = al;
@@ -547,48 +449,7 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
       }
     }
     __syncthreads();
-#if !MPNN_WGRAD_EARLY_FETCH
     if (node + nstep < Nend) fetch(node + nstep);  // next residue's loads fly under the MFMAs
-#endif
-#if MPNN_WGRAD_X32
-    // v_mfma_f32_16x16x16_f16 takes the same 16 cycles as the 16x16x32 form (tools/ubench/mfma_dep.hip): two column
-    // tiles (32 edges) go into ONE instruction - which edge sits at which k index is free as long as both operands
-    // agree, so the low half of a lane's 8 k values is its share of tile 2 cc and the high half that of tile 2 cc + 1
-    // (zeros when the neighbourhood has no such tile).  The LDS reads are those of the half-depth form.
-#pragma unroll
-    for (int cc = 0; cc < (KTM + 1) / 2; ++cc) {
-      if (2 * cc < KT) {
-        constexpr h4 zero4 = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
-        const bool two = 2 * cc + 1 < KTM && 2 * cc + 1 < KT;  // wave-uniform
-        auto pair = [&](const _Float16* row) {
-          const h4 lo = *reinterpret_cast<const h4*>(row + 32 * cc + 4 * g);
-          h4 hi = zero4;
-          if (2 * cc + 1 < KTM) {
-            hi = *reinterpret_cast<const h4*>(row + 32 * cc + 16 + 4 * g);
-            if (!two) hi = zero4;
-          }
-          return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        };
-        h8 ah[TT], al[TT];
-#pragma unroll
-        for (int i = 0; i < TT; ++i) {
-          ah[i] = pair(&sA[0][16 * (TT * wave + i) + col][0]);
-          al[i] = pair(&sA[1][16 * (TT * wave + i) + col][0]);
-        }
-#pragma unroll
-        for (int j = 0; j < MPNN_NT; ++j) {
-          const h8 bh = pair(&sB[0][16 * j + col][0]);
-          const h8 bl = pair(&sB[1][16 * j + col][0]);
-#pragma unroll
-          for (int i = 0; i < TT; ++i) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][j], 0, 0, 0);
-          }
-        }
-      }
-    }
-#else
     for (int c = 0; c < KT; ++c) {
       h4 ah[TT], al[TT];
 #pragma unroll
@@ -608,7 +469,6 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
         }
       }
     }
-#endif
   }
   // this workgroup's partial [128 x 128 | 128 bias sums] -> workspace (plain stores; k_wgrad_reduce adds them up:
   // 2^23 same-address-set atomics per launch from 512 workgroups cost more than the whole contraction)

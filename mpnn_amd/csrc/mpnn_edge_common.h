@@ -13,16 +13,12 @@ namespace {
 // LAUNDER_FLAT: the pointer itself goes through the asm; reads through it become flat_load.  Kept for ONE stream, the
 // edge-update backward's W11b^T ring, where the flat form measured FASTER (1.665 against 1.81 ms per training step).
 #define LAUNDER_FLAT(p) asm volatile("" : "+s"(p))
-#ifdef MPNN_LAUNDER_PTR  // round-1 form everywhere (A/B builds)
-#define LAUNDER(p) asm volatile("" : "+s"(p))
-#else
 #define LAUNDER(p)                                    \
   do {                                                \
     int z__;                                          \
     asm volatile("s_mov_b32 %0, 0" : "=s"(z__));      \
     (p) += z__;                                       \
   } while (0)
-#endif
 #define GLOBAL(p) ((const __attribute__((address_space(1))) std::remove_cv_t<std::remove_pointer_t<decltype(p)>>*)(p))
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 
@@ -76,14 +72,12 @@ struct ResidueRange {
 };
 __device__ __forceinline__ ResidueRange residue_range(int N, int waves, int wave) {
   const int G = gridDim.x, b = blockIdx.x;
-#ifndef MPNN_NO_XCD_MAP
   if (G >= 8 && (G & 7) == 0) {
     const int chunk = (N + 7) >> 3;
     const int lo = (b & 7) * chunk;
     const int hi = lo + chunk < N ? lo + chunk : N;
     return ResidueRange{lo + (b >> 3) * waves + wave, hi, (G >> 3) * waves};
   }
-#endif
   return ResidueRange{b * waves + wave, N, G * waves};
 }
 

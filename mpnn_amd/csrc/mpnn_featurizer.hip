@@ -11,11 +11,7 @@ MPNN_KERNELS_BEGIN
 // sqrtf's software refinement (cmp / cndmask / fma: ~20 instructions, 75 roots per residue) was 45 % of the
 // featurizer's vector instructions.
 __device__ __forceinline__ float rbf_distance(float d2) {
-#ifdef MPNN_RBF_EXACT_SQRT
-  return sqrtf(d2);
-#else
   return __builtin_amdgcn_sqrtf(d2);
-#endif
 }
 
 
@@ -304,9 +300,6 @@ __global__ void k_pos_table(const float* __restrict__ W, const float* __restrict
 #ifndef MPNN_FEAT_RING
 #define MPNN_FEAT_RING 4  // weight fragments in flight ahead of their MFMAs
 #endif
-#ifndef MPNN_FEAT_STAGGER
-#define MPNN_FEAT_STAGGER 1
-#endif
 #ifndef MPNN_FEAT_PERSISTENT
 #define MPNN_FEAT_PERSISTENT 1  // K <= 48: k_edge_features_ring (weights through LDS, once per eight residues)
 #endif
@@ -580,7 +573,7 @@ k_edge_features_ring(const float* __restrict__ atoms, const int* __restrict__ E_
 #pragma unroll
         for (int c = 0; c < KT; ++c) split_pair(x0[c], x1[c], bf[c]);
       };
-      const bool early = !MPNN_FEAT_STAGGER || wave < FEAT_WAVES / 2;
+      const bool early = wave < FEAT_WAVES / 2;
       if (early) operand();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the images in flight have landed
       __syncthreads();

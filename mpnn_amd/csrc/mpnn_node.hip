@@ -25,9 +25,6 @@ constexpr int WSPLIT = MPNN_NT * NKK * 2 * 64;  // h8 elements of one packed 128
 #ifndef MPNN_NODE_LDS_RING
 #define MPNN_NODE_LDS_RING 6  // measured: 3 -> 0.335, 6 -> 0.309, 10 / 15 -> 0.309 ms per step (7 launches, B32 x L512)
 #endif
-#ifndef MPNN_NODE_DMA_SPREAD
-#define MPNN_NODE_DMA_SPREAD 1
-#endif
 #ifndef MPNN_NODE_WAVES
 #define MPNN_NODE_WAVES 4  // waves (16-node tiles) per workgroup of k_node_update
 #endif
@@ -123,15 +120,9 @@ k_node_update(const float* __restrict__ hV_in, const float* __restrict__ gsum, c
   auto prefetch = [&]() {
     if (k + 1 < nmat) stage_matrix(matrix(k + 1), lds + ((k + 1) & 1) * WSPLIT);
   };
-#if MPNN_NODE_DMA_SPREAD
   auto prefetch_part = [&](int part) {
     if (k + 1 < nmat) stage_matrix_part(matrix(k + 1), lds + ((k + 1) & 1) * WSPLIT, part);
   };
-#else
-  auto prefetch_part = [&](int part) {
-    if (part == 0) prefetch();
-  };
-#endif
   auto retire = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

@@ -4,18 +4,12 @@
 //     dW[o][i] += sum_n dY[n][o] X[n][i],   db[o] += sum_n dY[n][o]          (autograd of reference :78-93, :151-155)
 // The shape is "tiny output, long reduction" (128..512 x 128..512 outputs over ~10^4 residues), which library GEMMs
 // serve badly (measured 91 us per call through hipBLASLt's 32x32 macro-tile at 10240 residues).  Here the reduction
-// is split over workgroups; each wave keeps 2 x 8 output tiles in registers, feeds v_mfma_f32_16x16x4_f32 (exact
-// fp32 products) straight from global memory, and stores its partial tile to a workspace that a second small
-// kernel adds up (per-element atomics from every workgroup cost more than the contraction itself).
+// is split over workgroups; each wave keeps 2 x 8 output tiles in registers, feeds split-f16 MFMAs straight from
+// global memory, and stores its partial tile to a workspace that a second small kernel adds up in a fixed order.
 #include "mpnn_bwd_common.h"
 #include <mutex>
 
-constexpr int NW_PART = 128 * 128 + 128;
-#ifdef MPNN_NODE_WGRAD_F32  // exact fp32 products on v_mfma_f32_16x16x4_f32 (round-1 form)
-#define MPNN_NODE_WGRAD_KERNEL k_node_wgrad
-#else
-#define MPNN_NODE_WGRAD_KERNEL k_node_wgrad_split
-#endif  // floats of one workgroup partial (tile | bias sums)
+constexpr int NW_PART = 128 * 128 + 128;  // floats of one workgroup partial (tile | bias sums)
 
 // up to WG_JOBS weight gradients over the same rows in one launch (all linears of one node update): the job table
 // travels by value; blockIdx.y enumerates the 128x128 output blocks of all jobs (job j owns blk0[j] .. blk0[j+1])
@@ -37,76 +31,13 @@ __device__ __forceinline__ int find_job(const WgradJobs& jb, int blk) {
   return j;
 }
 
-__global__ void __launch_bounds__(256)
-k_node_wgrad(WgradJobs jb, int N, int rows_per_wg, float* __restrict__ part) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane >> 4, col = lane & 15;
-  const int job = find_job(jb, blockIdx.y);
-  const int local = blockIdx.y - jb.blk0[job];
-  const float* __restrict__ dY = jb.dY[job];
-  const float* __restrict__ X = jb.X[job];
-  const int ldy = jb.ldy[job], out_f = jb.out_f[job], ldx = jb.ldx[job], in_f = jb.in_f[job];
-  const int o0 = (local % jb.ny[job]) * 128 + 32 * wave, i0 = (local / jb.ny[job]) * 128;
-  const int r0 = blockIdx.x * rows_per_wg;
-  const int r1 = min(N, r0 + rows_per_wg);
-  f32x4 acc[2][8];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bs[2] = {0.f, 0.f};
-  bool ov[2], iv[8];
-#pragma unroll
-  for (int a = 0; a < 2; ++a) ov[a] = o0 + 16 * a + col < out_f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) iv[j] = i0 + 16 * j + col < in_f;
-  // batches of 8 k-steps (32 rows): all 80 loads of a batch are issued before its MFMAs (the operands are single
-  // dwords at row stride, so latency, not bandwidth, is what has to be hidden)
-  for (int n = r0; n < r1; n += 32) {
-    float a[8][2], b[8][8];
-#pragma unroll
-    for (int s8 = 0; s8 < 8; ++s8) {
-      const int row = n + 4 * s8 + g;
-      const bool rv = row < r1;
-      const float* dy = dY + (size_t)row * ldy + o0 + col;
-      const float* x = X + (size_t)row * ldx + i0 + col;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) a[s8][q] = (rv && ov[q]) ? dy[16 * q] : 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) b[s8][j] = (rv && iv[j]) ? x[16 * j] : 0.f;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s8 = 0; s8 < 8; ++s8)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        bs[q] += a[s8][q];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[q][j] = mfma4(a[s8][q], b[s8][j], acc[q][j]);
-      }
-  }
-  // partial tile of this workgroup -> workspace; k_node_wgrad_reduce adds the row chunks up
-  float* P = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NW_PART;
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) P[(32 * wave + 16 * q + 4 * g + r) * 128 + 16 * j + col] = acc[q][j][r];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const float v = quarter_sum(bs[q]);
-    if (g == 0) P[128 * 128 + 32 * wave + 16 * q + col] = v;
-  }
-}
-
-// The same contraction on the f16 matrix pipe (default): 32 rows per MFMA k-step instead of 4, three split products per
-// tile (a_lo b_hi + a_hi b_lo + a_hi b_hi, as everywhere else in the library) = 48 v_mfma_f32_16x16x32_f16 per 32 rows
-// and wave against 128 v_mfma_f32_16x16x4_f32, which run at the fp32 vector rate and made this kernel compute-bound
-// (46 us per launch at 10 240 rows).  The gradient operand is tiny (loss / 2000): each 32-row batch is scaled by an
+// The contraction on the f16 matrix pipe: 32 rows per MFMA k-step, three split products per tile (a_lo b_hi + a_hi b_lo
+// + a_hi b_hi, as everywhere else in the library) = 48 v_mfma_f32_16x16x32_f16 per 32 rows and wave (round 1 used 128
+// v_mfma_f32_16x16x4_f32, which run at the fp32 vector rate and made this kernel compute-bound: 46 us per launch at
+// 10 240 rows).  The gradient operand is tiny (loss / 2000): each 32-row batch is scaled by an
 // exact power of two taken from the wave's largest |dY| before the split, and its partial tile is scaled back when it
-// is added to the fp32 accumulators.  Same operand addressing as above, with k = 8 g + i: lane (col, g) holds rows
-// n + 8 g .. n + 8 g + 7 of its feature column.
+// is added to the fp32 accumulators.  Operand addressing: k = 8 g + i, i.e. lane (col, g) holds rows
+// n + 8 g .. n + 8 g + 7 of its feature column (single dwords at row stride: latency, not bandwidth, is to be hidden).
 __global__ void __launch_bounds__(256)
 k_node_wgrad_split(WgradJobs jb, int N, int rows_per_wg, float* __restrict__ part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -646,7 +577,7 @@ static int launch_node_wgrads(const WgradJobs& jb, int n_rows, float* workspace,
   int rows = 32;  // rows per workgroup: as many row chunks as the workspace and ~256 workgroups per block allow
   while ((n_rows + rows - 1) / rows > (max_x < 256 ? max_x : 256)) rows *= 2;
   const int nx = (n_rows + rows - 1) / rows;
-  hipLaunchKernelGGL(MPNN_NODE_WGRAD_KERNEL, dim3(nx, nblk), dim3(256), 0, st, jb, n_rows, rows, workspace);
+  hipLaunchKernelGGL(k_node_wgrad_split, dim3(nx, nblk), dim3(256), 0, st, jb, n_rows, rows, workspace);
   hipLaunchKernelGGL(k_node_wgrad_reduce, dim3((NW_PART + 63) / 64, nblk), dim3(256), 0, st, workspace, nx, jb);
   MPNN_LAUNCH_CHECK();
 }

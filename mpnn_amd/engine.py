@@ -806,20 +806,19 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
         head = [ptr(hVs[n_dec]), ptr(pw.Wlogit), ptr(pw.blogit), ptr(lb), pw.n_letters, None, 0, float(temperature),
                 int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(designable), ptr(S_in), ptr(S_out), ptr(log_probs), ptr(pw.TS),
                 pw.TS.shape[1], n_dec, A_rows, A_ld, A_off, st]
-        # MPNN_SAMPLE_LAUNCHES: "layer" (default) = one launch per decoder layer and level, the last one also drawing
-        # (mpnn_dec_layer_sample_subset); "layer/head" = the draw in a launch of its own (mpnn_sample_subset);
-        # "layer+draw" = the last layer and the draw through mpnn_decode_level; "level" = one launch per level
-        # (mpnn_decode_level).  The two mpnn_decode_level forms measured SLOWER on MI355X (one L = 512 sample: 6.7 ms
-        # for "layer/head", 7.3 ms / 8.1 ms).  "split" = message / node update / head launches
-        # "layer/head": as "layer" with the draw in a launch of its own (the last layer's launch draws by default)
-        # default "run": the whole level loop in ONE library call (mpnn_decode_run: the "layer" mode's launches issued
-        # from C; the Python loop below costs ~11 us of host time per launch, more than the kernels take)
+        # MPNN_SAMPLE_LAUNCHES (the default is what ships; the others exist for tests and A/B timing):
+        #   "run"        the whole level loop in ONE library call (mpnn_decode_run): per level one launch per decoder
+        #                layer, the last one also drawing (mpnn_dec_layer_sample_subset)
+        #   "run/head"   the same with the draw in a launch of its own (mpnn_sample_subset)
+        #   "layer", "layer/head"   the same launches, issued from this Python loop (round 2's form: equal device time,
+        #                more host time)
+        #   "split"      message / node update / head launches (the only form for K > 48: four column tiles)
         mode = os.environ.get("MPNN_SAMPLE_LAUNCHES", "run")
-        run_in_c = mode in ("run", "run/head")
-        if run_in_c:
-            mode = "layer" if mode == "run" else "layer/head"
-        head_fused = mode == "layer" and plans[-1][2][37] == 0   # the last decoder layer has no projections
-        if mode == "layer/head":
+        if mode not in ("run", "run/head", "layer", "layer/head", "split"):
+            raise ValueError(f"MPNN_SAMPLE_LAUNCHES={mode!r}: expected run, run/head, layer, layer/head or split")
+        run_in_c = mode.startswith("run")
+        head_fused = mode in ("run", "layer") and plans[-1][2][37] == 0   # the last decoder layer has no projections
+        if mode != "split":
             mode = "layer"
         if os.environ.get("MPNN_SAMPLE_UNFUSED") == "1" or K > 48:
             mode = "split"  # the fused level kernels give a workgroup four residues x three column tiles (K <= 48)
@@ -833,39 +832,30 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
         f_msg = getattr(lib, _lib.entry("mpnn_dec_message_subset"))
         f_node = getattr(lib, _lib.entry("mpnn_node_update_subset"))
         f_head = lib.mpnn_sample_subset
-        f_level = getattr(lib, _lib.entry("mpnn_decode_level"))
         if _lib._profile is not None:  # bench.py's per-entry-point timing goes through the generic wrapper
             f_layer = lambda *a: (call("mpnn_dec_layer_subset", *a), 0)[1]
             f_last = lambda *a: (call("mpnn_dec_layer_sample_subset", *a), 0)[1]
             f_msg = lambda *a: (call("mpnn_dec_message_subset", *a), 0)[1]
             f_node = lambda *a: (call("mpnn_node_update_subset", *a), 0)[1]
             f_head = lambda *a: (call("mpnn_sample_subset", *a), 0)[1]
-            f_level = lambda *a: (call("mpnn_decode_level", *a), 0)[1]
-        layers = (_lib.LevelLayer * n_dec)()
-        for l, lw in enumerate(pw.dec):
-            grp = pw.g_dec[l]
-            y = layers[l]
-            y.P, y.ldp, y.offP = ptr(PA[l]), 2 * H, 0
-            y.RowA, y.lda, y.offA = ptr(PA[l]), 2 * H, H
-            y.offEnc = base + 2 * H + H * l
-            y.W1b_packed, y.W2_packed, y.b2 = ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"])
-            y.hV_in, y.hV_out = ptr(hVs[l]), ptr(hVs[l + 1])
-            y.W3_packed, y.b3, y.ln1_w, y.ln1_b = ptr(lw["W3"]), ptr(lw["b3"]), ptr(lw["ln1w"]), ptr(lw["ln1b"])
-            y.Win_packed, y.b_in, y.Wout8_packed, y.b_out = ptr(lw["Win"]), ptr(lw["bin"]), ptr(lw["Wout8"]), ptr(lw["bout"])
-            y.ln2_w, y.ln2_b, y.scale = ptr(lw["ln2w"]), ptr(lw["ln2b"]), lw["scale"]
-            y.Wproj_packed, y.bproj, y.nproj = ptr(grp[0]), ptr(grp[1]), grp[2]
-            y.PQ = ptr(PA[l + 1]) if grp[2] else None
-        plan = torch.empty(1024, device=dev, dtype=torch.uint8)  # MPNN_DECODE_PLAN_BYTES
-        if mode in ("level", "layer+draw"):
-            call("mpnn_decode_plan", layers, n_dec, ptr(plan), st)
-        level = [ptr(enc["hE"]), ptr(PQenc), PQenc.shape[1], ptr(rank), ptr(enc["E_idx32"]), ptr(mask_s),
-                 ptr(enc["edge_mask"]), None, 0, N, L, K, float(K), ptr(plan), 0 if mode == "level" else n_dec - 1, n_dec, ptr(pw.Wlogit), ptr(pw.blogit), ptr(lb),
-                 pw.n_letters, float(temperature), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(designable), ptr(S_in),
-                 ptr(S_out), ptr(log_probs), ptr(pw.TS), pw.TS.shape[1], st]
         list_ptr = perm.data_ptr()
         start = 0
         rc = 0
-        if run_in_c and mode == "layer" and K <= 48 and plans[-1][2][37] == 0:
+        if run_in_c and mode == "layer" and plans[-1][2][37] == 0:
+            layers = (_lib.LevelLayer * n_dec)()
+            for l, lw in enumerate(pw.dec):
+                grp = pw.g_dec[l]
+                y = layers[l]
+                y.P, y.ldp, y.offP = ptr(PA[l]), 2 * H, 0
+                y.RowA, y.lda, y.offA = ptr(PA[l]), 2 * H, H
+                y.offEnc = base + 2 * H + H * l
+                y.W1b_packed, y.W2_packed, y.b2 = ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"])
+                y.hV_in, y.hV_out = ptr(hVs[l]), ptr(hVs[l + 1])
+                y.W3_packed, y.b3, y.ln1_w, y.ln1_b = ptr(lw["W3"]), ptr(lw["b3"]), ptr(lw["ln1w"]), ptr(lw["ln1b"])
+                y.Win_packed, y.b_in, y.Wout8_packed, y.b_out = ptr(lw["Win"]), ptr(lw["bin"]), ptr(lw["Wout8"]), ptr(lw["bout"])
+                y.ln2_w, y.ln2_b, y.scale = ptr(lw["ln2w"]), ptr(lw["ln2b"]), lw["scale"]
+                y.Wproj_packed, y.bproj, y.nproj = ptr(grp[0]), ptr(grp[1]), grp[2]
+                y.PQ = ptr(PA[l + 1]) if grp[2] else None
             c_counts = (ctypes.c_int * len(counts))(*counts)
             call("mpnn_decode_run", ptr(enc["hE"]), ptr(PQenc), PQenc.shape[1], ptr(rank), ptr(enc["E_idx32"]),
                  ptr(mask_s), ptr(enc["edge_mask"]), list_ptr, c_counts, len(counts), N, L, K, float(K), layers, n_dec,
@@ -878,18 +868,7 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
         for cnt_l in counts_loop:
             p_nodes = list_ptr + 4 * start
             start += cnt_l
-            if mode == "level":
-                level[7], level[8] = p_nodes, cnt_l
-                rc = rc or f_level(*level)
-                continue
-            if mode == "layer+draw":  # the last layer's launch also draws (mpnn_decode_level from layer n_dec - 1)
-                for msg, node, layer in plans[:-1]:
-                    layer[17], layer[18] = p_nodes, cnt_l
-                    rc = rc or f_layer(*layer)
-                level[7], level[8] = p_nodes, cnt_l
-                rc = rc or f_level(*level)
-                continue
-            if mode == "layer" and head_fused and K <= 48:
+            if mode == "layer" and head_fused:
                 for msg, node, layer in plans[:-1]:
                     layer[17], layer[18] = p_nodes, cnt_l
                     rc = rc or f_layer(*layer)

@@ -183,13 +183,17 @@ def _zeros(dev, *shape):
     return _ZEROS.take(*shape)
 
 
-def _workspace(dev):
-    """Per-device scratch for the weight-gradient kernels' partial sums (calls on one stream reuse it in order)."""
+def _workspace(dev, n_rows=0):
+    """Per-device scratch for the partial sums of the weight-gradient, backward, head and loss kernels (calls on one
+    stream reuse it in order).  n_rows: rows (residues) of the call, for the entry points whose need grows with them."""
+    lib = _lib.load()
+    need = max(lib.mpnn_workspace_bytes(b"mpnn_edge_wgrad", 1 << 30, 1),
+               lib.mpnn_workspace_bytes(b"mpnn_enc_edge_update_bwd", 0, 0),
+               lib.mpnn_workspace_bytes(b"mpnn_logits_log_softmax_bwd", int(n_rows), 0),
+               lib.mpnn_workspace_bytes(b"mpnn_node_update_bwd", int(n_rows), 0)) // 4
     ws = _WS.get(dev)
-    if ws is None:
-        # the largest request of any call in a step: the edge weight gradient at full width (mpnn_workspace_bytes)
-        nbytes = _lib.load().mpnn_workspace_bytes(b"mpnn_edge_wgrad", 1 << 30, 1)
-        ws = _WS[dev] = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+    if ws is None or ws.numel() < need:
+        ws = _WS[dev] = torch.empty(need, device=dev, dtype=torch.float32)
     return ws
 
 
@@ -561,7 +565,7 @@ class NodeUpdateFn(torch.autograd.Function):
         x1, d_o, d_dh = torch.empty(N, H, device=dev), torch.empty(N, H, device=dev), torch.empty(N, H, device=dev)
         hid, d_a = torch.empty(N, 4 * H, device=dev), torch.empty(N, 4 * H, device=dev)
         dvec = _zeros(dev, 5 * H)
-        ws = _workspace(dev)
+        ws = _workspace(dev, N)
         call("mpnn_node_update_bwd", ptr(dY), ptr(dPQb), ptr(x1pre), ptr(a_pre), ptr(x2pre), ptr(cnt), 0.0, ptr(mask),
              ptr(ln1w.detach().contiguous()), ptr(ln1b.detach().contiguous()), ptr(ln2w.detach().contiguous()),
              float(scale), ptr(wprojT), nproj, ptr(woutT), ptr(winT), ptr(w3T), N, ptr(d_hV_in), ptr(d_gsum), ptr(x1),
@@ -708,7 +712,7 @@ class HeadFn(torch.autograd.Function):
         d_hV = torch.empty_like(hV)
         dW = _zeros(hV.device, n_letters, H)
         db = _zeros(hV.device, n_letters)
-        ws = _workspace(hV.device)
+        ws = _workspace(hV.device, N)
         call("mpnn_logits_log_softmax_bwd", ptr(d_logp), ptr(logp), ptr(hV), ptr(W), n_letters, N, ptr(d_hV), ptr(dW),
              ptr(db), ptr(ws), ws.numel(), stream_ptr())
         return d_hV, dW, db

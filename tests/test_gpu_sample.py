@@ -128,7 +128,7 @@ def test_low_temperature_is_argmax_and_seed_reproducible():
     assert not torch.equal(c["S"], a["S"])
 
 
-@pytest.mark.parametrize("mode", ["run", "run/head", "layer", "layer/head", "layer+draw", "level", "split"])
+@pytest.mark.parametrize("mode", ["run", "run/head", "layer", "layer/head", "split"])
 def test_every_launch_mode_is_bit_reproducible(monkeypatch, mode):
     """No sum of the sampler meets by atomics (a residue's column-tile sums are added in tile order, in LDS or from
     per-tile rows in HBM): the same call twice returns the same sequences AND the same log-probs, bit for bit, in
@@ -166,10 +166,12 @@ def test_draw_frequencies_follow_the_model_distribution():
 
 
 def test_launch_modes_agree(monkeypatch):
-    """The sampler's three launch granularities (per level: mpnn_decode_level; per decoder layer and level:
-    mpnn_dec_layer_subset + mpnn_sample_subset; message / node update / head) run the same arithmetic up to the order
-    in which a residue's three column-tile sums meet (fp32 atomics, in LDS or in HBM).  Two structures, ragged, so that
-    levels span the residues-per-workgroup choices (n_samples 2 and 40)."""
+    """The sampler's launch forms - the whole level loop in one library call (mpnn_decode_run, the default), the same
+    launches issued from Python, the draw fused into the last layer's launch or in a launch of its own, and the
+    message / node update / head form - run the same arithmetic; a residue's three column-tile sums are added in tile
+    order everywhere, so the fused forms agree bit for bit and the split form to rounding (its tiles meet after a
+    trip through HBM in another association).  Two structures, ragged, so that levels span the
+    residues-per-workgroup choices (n_samples 2 and 40)."""
     from mpnn_amd.synthetic import synthetic_batch
 
     model = build(dict(k_neighbors=48, use_virtual_center=True))
@@ -178,21 +180,18 @@ def test_launch_modes_agree(monkeypatch):
     args = (b["X"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
     for n_samples in (2, 40):
         outs = {}
-        for mode in ("run", "run/head", "layer", "layer/head", "layer+draw", "level", "split"):
+        for mode in ("run", "run/head", "layer", "layer/head", "split"):
             monkeypatch.setenv("MPNN_SAMPLE_LAUNCHES", mode)
             outs[mode] = model.sample(*args, S_true=b["S"], n_samples=n_samples, temperature=0.3, seed=7)
-        # the default ("layer": the last layer's launch also draws) against the draw in a launch of its own: the same
-        # arithmetic on the same values, bit for bit (neighbour sums meet in LDS in both)
-        assert torch.equal(outs["layer"]["S"], outs["layer/head"]["S"])
-        assert float((outs["layer"]["log_probs"] - outs["layer/head"]["log_probs"]).abs().max()) <= 1e-5
-        # the default ("run": mpnn_decode_run issues the "layer" mode's launches from C) and its separate-head form
-        for other in ("run", "run/head"):
-            assert torch.equal(outs["layer"]["S"], outs[other]["S"]), other
-            assert float((outs["layer"]["log_probs"] - outs[other]["log_probs"]).abs().max()) <= 1e-5, other
-        for other in ("layer+draw", "level", "split"):
-            same = (outs["layer"]["S"] == outs[other]["S"]).float().mean()
-            assert float(same) > 0.99, other  # a draw can flip where u lands within an ulp of a CDF step
-            agree = (outs["layer"]["S"] == outs[other]["S"]).all(-1).all(-1)  # samples drawn identically
-            assert bool(agree.any()), other
-            d = (outs["layer"]["log_probs"][agree] - outs[other]["log_probs"][agree]).abs().max()
-            assert float(d) <= 1e-5, other
+        for other in ("run/head", "layer", "layer/head"):
+            assert torch.equal(outs["run"]["S"], outs[other]["S"]), other
+            assert float((outs["run"]["log_probs"] - outs[other]["log_probs"]).abs().max()) <= 1e-5, other
+        same = (outs["run"]["S"] == outs["split"]["S"]).float().mean()
+        assert float(same) > 0.99  # a draw can flip where u lands within an ulp of a CDF step
+        agree = (outs["run"]["S"] == outs["split"]["S"]).all(-1).all(-1)  # samples drawn identically
+        assert bool(agree.any())
+        d = (outs["run"]["log_probs"][agree] - outs["split"]["log_probs"][agree]).abs().max()
+        assert float(d) <= 1e-5
+    monkeypatch.setenv("MPNN_SAMPLE_LAUNCHES", "level")
+    with pytest.raises(ValueError, match="MPNN_SAMPLE_LAUNCHES"):
+        model.sample(*args, S_true=b["S"], n_samples=2, temperature=0.3, seed=7)
