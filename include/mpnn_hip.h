@@ -289,6 +289,20 @@ int mpnn_message_bwd(int dec, const float* dgsum, const float* a1_frag, const fl
                      int B, int L, int K, float* da2_frag, float* da1_rows, float* dP, float* dE_frag, int accumulate,
                      float* amax2, int w_valid, void* stream);
 
+/* mpnn_message_bwd AND its two weight-gradient contractions (dW2 += da2 (x) gelu(a1), db2 += sum da2,
+ * dW1b += rows (x) e) in one kernel, for K <= 48 (above: mpnn_message_bwd + 2 x mpnn_edge_wgrad): da2 is never written,
+ * a1 / hE / the rows are read once instead of twice (reference: the autograd of model_utils.py:241-243 / :112-115,
+ * whose eager form materialises every one of these tensors).  dW2 / db2 / dW1b are ACCUMULATED INTO (zero them for a
+ * plain gradient).  The f16 hi/lo operand splits use launch-wide power-of-two scales from bounds (1.13 max |dgsum|,
+ * times max_k sum_o |W2[o][k]| for the rows), found by a small pre-launch: no host value is needed.
+ * workspace: 64 + 33024 floats per workgroup, one workgroup per CU at most (mpnn_workspace_bytes); partial sums are
+ * added in a fixed order - bit-identical from run to run. */
+int mpnn_message_bwd_fused(int dec, const float* dgsum, const float* a1_frag, const float* a2_frag,
+                           const float* hE_frag, const int32_t* E_idx32, const float* mask, const float* edge_mask,
+                           const float* W2T_packed, const float* W1bT_packed, int B, int L, int K, float* da1_rows,
+                           float* dP, float* dE_frag, int accumulate, int w_valid, float* dW2, float* db2, float* dW1b,
+                           float* workspace, int workspace_floats, void* stream);
+
 /* Backward of the edge update: LayerNorm', W13^T, W12^T, W11b^T; dln[0:128] += d ln_w, dln[128:256] += d ln_b.
  * dE_frag may alias dy_frag.  amax3[0..2] (zero them first) receive max |dz|, |da2|, |da1 rows|.
  * workspace: >= 256 floats per workgroup (one workgroup per CU at most: 65536 floats always suffice) for the

@@ -491,13 +491,14 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
 // dW[i] += sum_w part[w][i]: 16 slices of the workgroup partials per element, met in LDS in slice order (no atomics:
 // the same bits on every run)
 __global__ void __launch_bounds__(256)
-k_wgrad_reduce(const float* __restrict__ part, int nparts, float* __restrict__ dW, float* __restrict__ db) {
+k_wgrad_reduce(const float* __restrict__ part, int nparts, size_t stride, float* __restrict__ dW,
+               float* __restrict__ db) {
   __shared__ float sl[16][17];
   const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + el;
   float s = 0.f;
   if (i < WG_PART)
-    for (int w = slice; w < nparts; w += 16) s += part[(size_t)w * WG_PART + i];
+    for (int w = slice; w < nparts; w += 16) s += part[(size_t)w * stride + i];
   sl[slice][el] = s;
   __syncthreads();
   if (slice == 0 && i < WG_PART) {
@@ -508,6 +509,240 @@ k_wgrad_reduce(const float* __restrict__ part, int nparts, float* __restrict__ d
       dW[i] += t;
     else if (db)
       db[i - MPNN_H * MPNN_H] += t;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Message backward with BOTH weight-gradient contractions fused in (K <= 48): mpnn_message_bwd + two mpnn_edge_wgrad
+// passes in one kernel, so da2 never exists in memory and a1 / hE / the da1 rows are not re-read by separate
+// contraction launches (per message MLP and step: 6 instead of 10 edge tensors of traffic).
+//
+// The chain kernels give a residue to ONE wave (weights in LDS, activations in registers).  A weight gradient is a sum
+// over ALL residues of an outer product whose 128 x 128 fp32 accumulator no single wave can hold, so here a residue
+// belongs to the WORKGROUP: wave w owns feature tile w (16 of the 128 features) of every tensor, keeps the 16 rows of
+// W2^T and W1b^T that produce its tile in REGISTERS (the A operands of the chain's two GEMMs) and its 16 x 128 row
+// blocks of dW2 and dW1b as accumulators.  Activations travel between the waves through LDS in two forms:
+//   Bf  [k-step][column tile][hi | lo][lane]   the B fragments of the next GEMM (k = features: every wave needs all),
+//   sA / sB [hi | lo][feature][edge]           f16 planes with the EDGES contiguous: the MFMA k dimension of the
+//                                              contractions dW[o][i] += sum_e A[e][o] B[e][i] (as in k_wgrad).
+// Per residue: da2 = gelu'(a2) dgsum w -> (barrier) -> dg1 = W2^T da2 | dW2 += da2 (x) gelu(a1) -> da1 = dg1 gelu'(a1),
+// dP, the s-scaled rows for the gather -> (barrier: largest |row|) -> (barrier) -> dE (+)= W1b^T rows |
+// dW1b += rows (x) e.  Gradient operands are scaled by an exact power of two before their f16 hi/lo split (da2: from
+// the bound 1.13 max |dgsum_i|, which every wave computes for itself; the rows: from their exact workgroup maximum).
+// Per-workgroup partial sums [2][128 x 128 + 128] go to the workspace; k_wgrad_reduce adds them in a fixed order.
+// ---------------------------------------------------------------------------
+constexpr int FB_WAVES = 8;
+constexpr int FB_LDK = 16 * 3 + 4;  // padded edge stride (halves) of the planes, as WG_LDK of k_wgrad at KTM = 3
+
+// scales[0] = max |dgsum| (float bits), scales[1] = max_k sum_o |W2[o][k]| (float bits); scales[] zeroed before.
+__global__ void __launch_bounds__(256)
+k_fused_scales(const float* __restrict__ dgsum, size_t n, const h8* __restrict__ W2T, unsigned* __restrict__ scales) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    m = fmaxf(m, fabsf(dgsum[i]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(&scales[0], (unsigned)__float_as_int(m));  // a maximum: order-independent
+  if (blockIdx.x == 0 && threadIdx.x < MPNN_H) {
+    // row `col` of output tile `to` of W2^T lives in lanes col, 16 + col, 32 + col, 48 + col of every k-step
+    const int to = threadIdx.x >> 4, col = threadIdx.x & 15;
+    float sum = 0.f;
+    for (int kk = 0; kk < NKK; ++kk)
+      for (int g = 0; g < 4; ++g) {
+        const h8 hi = W2T[((to * NKK + kk) * 2 + 0) * 64 + 16 * g + col];
+        const h8 lo = W2T[((to * NKK + kk) * 2 + 1) * 64 + 16 * g + col];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum += fabsf((float)hi[q] + (float)lo[q]);
+      }
+    atomicMax(&scales[1], (unsigned)__float_as_int(sum));
+  }
+}
+
+template <int KT, bool DEC>
+__global__ void __launch_bounds__(FB_WAVES * 64)
+k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a1, const f32x4* __restrict__ a2,
+                    const f32x4* __restrict__ hE, const int* __restrict__ E_idx, const float* __restrict__ mask,
+                    const float* __restrict__ edge_mask, const h8* __restrict__ W2T, const h8* __restrict__ W1bT, int N,
+                    int L, int K, float* __restrict__ da1_nat, float* __restrict__ dP, f32x4* __restrict__ dE,
+                    int accumulate, int w_valid, const unsigned* __restrict__ scales, float* __restrict__ part) {
+  __shared__ h8 Bf[2][NKK][KT][2][64];
+  __shared__ _Float16 sA[2][2][MPNN_H][FB_LDK];
+  __shared__ _Float16 sB[2][2][MPNN_H][FB_LDK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  constexpr int Kp = KT * 16;
+  // launch-wide power-of-two scales from BOUNDS: |da2| <= 1.13 max |dgsum| (gelu' <= 1.13, w <= 1) and
+  // |rows| <= 1.13 |W2^T da2| <= 1.13 max_k sum_o |W2[o][k]| max |da2|.  A bound that is loose by 2^b costs b of the
+  // ~36 bits between the scaled maximum and the f16 subnormal step of the lo part.
+  const float m1 = __int_as_float((int)scales[0]) * 1.1293f;
+  const float m2 = m1 * __int_as_float((int)scales[1]) * 1.1293f;
+  const float sc1 = pow2_scale_from_bits((unsigned)__float_as_int(m1)), un1 = pow2_inverse(sc1);
+  const float sc2 = pow2_scale_from_bits((unsigned)__float_as_int(m2)), un2 = pow2_inverse(sc2);
+  // this wave's rows of the two transposed weights: the A fragments of its output tile, all k-steps
+  h8 w2h[NKK], w2l[NKK], w1h[NKK], w1l[NKK];
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) {
+    w2h[kk] = W2T[((wave * NKK + kk) * 2 + 0) * 64 + lane];
+    w2l[kk] = W2T[((wave * NKK + kk) * 2 + 1) * 64 + lane];
+    w1h[kk] = W1bT[((wave * NKK + kk) * 2 + 0) * 64 + lane];
+    w1l[kk] = W1bT[((wave * NKK + kk) * 2 + 1) * 64 + lane];
+  }
+  f32x4 accW2[MPNN_NT], accW1[MPNN_NT];
+#pragma unroll
+  for (int j = 0; j < MPNN_NT; ++j) accW2[j] = accW1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bacc = f32x4{0.f, 0.f, 0.f, 0.f};
+  // where this lane's share of a (feature tile, column tile) goes in the planes / in a B fragment
+  const int frow = 16 * wave + 4 * g + (col & 3);
+  const int bf_kk = wave >> 1, bf_half = (wave & 1) * 4;  // halves [bf_half, bf_half + 4) of k-step bf_kk
+
+  // the contraction of one stage: acc[j] += sum_e A[row block of this wave][e] B[tile j][e]  (scaled by the stage's sc)
+  auto contract = [&](int st, f32x4 (&acc)[MPNN_NT]) {
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      const h4 ah = *reinterpret_cast<const h4*>(&sA[st][0][16 * wave + col][16 * c + 4 * g]);
+      const h4 al = *reinterpret_cast<const h4*>(&sA[st][1][16 * wave + col][16 * c + 4 * g]);
+#pragma unroll
+      for (int j = 0; j < MPNN_NT; ++j) {
+        const h4 bh = *reinterpret_cast<const h4*>(&sB[st][0][16 * j + col][16 * c + 4 * g]);
+        const h4 bl = *reinterpret_cast<const h4*>(&sB[st][1][16 * j + col][16 * c + 4 * g]);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc[j], 0, 0, 0);
+      }
+    }
+  };
+  // this wave's tile of a gradient (already scaled) -> its halves of the next GEMM's B fragments and its plane rows
+  auto publish = [&](int st, const f32x4 (&x)[KT], const f32x4 (&bsrc)[KT], bool b_gelu) {
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      h4 hh, ll;
+      split4(x[c], hh, ll);
+      _Float16* bh = reinterpret_cast<_Float16*>(&Bf[st][bf_kk][c][0][lane]) + bf_half;
+      _Float16* bl = reinterpret_cast<_Float16*>(&Bf[st][bf_kk][c][1][lane]) + bf_half;
+      *reinterpret_cast<h4*>(bh) = hh;
+      *reinterpret_cast<h4*>(bl) = ll;
+      const int ecol = 16 * c + 4 * (col >> 2);
+      split4(quad_transpose(x[c]), hh, ll);
+      *reinterpret_cast<h4*>(&sA[st][0][frow][ecol]) = hh;
+      *reinterpret_cast<h4*>(&sA[st][1][frow][ecol]) = ll;
+      split4(quad_transpose(b_gelu ? gelu4(bsrc[c]) : bsrc[c]), hh, ll);
+      *reinterpret_cast<h4*>(&sB[st][0][frow][ecol]) = hh;
+      *reinterpret_cast<h4*>(&sB[st][1][frow][ecol]) = ll;
+    }
+  };
+  // y[c] = sum_k W^T[tile of this wave][k] X[k][column tile c], X from the B fragments of stage st
+  auto gemm = [&](int st, const h8 (&wh)[NKK], const h8 (&wl)[NKK], f32x4 (&y)[KT]) {
+#pragma unroll
+    for (int c = 0; c < KT; ++c) y[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        BFrag b;
+        b.hi = Bf[st][kk][c][0][lane];
+        b.lo = Bf[st][kk][c][1][lane];
+        y[c] = mfma_split(wh[kk], wl[kk], b, y[c]);
+      }
+  };
+
+  // loads of one residue that its FIRST phase needs; issued one residue ahead
+  f32x4 x2[KT], x1[KT], gs;
+  float s[KT], w[KT];
+  auto fetch_first = [&](int node) {
+    const int b = node / L;
+    const float mi = mask[node];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      const int e = 16 * c + col;
+      float em = 1.0f;
+      if (edge_mask && e < K) em = edge_mask[(size_t)node * K + e];
+      if (DEC) {
+        s[c] = mi * em;
+        w[c] = e < K ? (w_valid ? em : 1.0f) : 0.0f;
+      } else {
+        s[c] = 1.0f;
+        w[c] = e < K ? mi * mask[b * L + E_idx[(size_t)node * Kp + e]] * em : 0.0f;
+      }
+    }
+    const size_t off = (size_t)node * (MPNN_NT * KT * 64) + lane;
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      x2[c] = __builtin_nontemporal_load(&a2[off + (wave * KT + c) * 64]);
+      x1[c] = __builtin_nontemporal_load(&a1[off + (wave * KT + c) * 64]);
+    }
+    gs = *reinterpret_cast<const f32x4*>(dgsum + (size_t)node * MPNN_H + 16 * wave + 4 * g);
+  };
+
+  int node = blockIdx.x;
+  if (node < N) fetch_first(node);
+  for (; node < N; node += gridDim.x) {
+    const size_t off = (size_t)node * (MPNN_NT * KT * 64) + lane;
+    // ---- phase 1: da2 of this wave's feature tile; its B fragments and planes, the planes of gelu(a1)
+    f32x4 d2[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      d2[c] = gelu_grad4(x2[c]) * (gs * w[c]);
+      bacc += d2[c];
+      d2[c] *= sc1;
+    }
+    publish(0, d2, x1, true);
+    // the second phase's operands of THIS residue (needed one barrier from now)
+    f32x4 xe[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) xe[c] = __builtin_nontemporal_load(&hE[off + (wave * KT + c) * 64]);
+    __syncthreads();  // A: stage-0 fragments and planes complete (and stage 1 of the previous residue consumed)
+    // ---- phase 2: dg1 = W2^T da2; dW2 += da2 (x) gelu(a1); da1, dP, rows
+    f32x4 y[KT];
+    gemm(0, w2h, w2l, y);
+    f32x4 ps = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      y[c] *= gelu_grad4(x1[c]) * un1;
+      ps += y[c];
+      if (DEC) y[c] *= s[c];
+      __builtin_nontemporal_store(y[c], reinterpret_cast<f32x4*>(da1_nat + ((size_t)node * Kp + 16 * c + col) * MPNN_H +
+                                                                  16 * wave + 4 * g));
+      y[c] *= sc2;
+    }
+    ps = column_sum4(ps);
+    if (col == 0) *reinterpret_cast<f32x4*>(dP + (size_t)node * MPNN_H + 16 * wave + 4 * g) = ps;
+    publish(1, y, xe, false);
+    contract(0, accW2);
+    f32x4 pe[KT];
+    if (accumulate) {
+#pragma unroll
+      for (int c = 0; c < KT; ++c) pe[c] = dE[off + (wave * KT + c) * 64];
+    }
+    __syncthreads();  // B: stage-1 fragments and planes complete (and stage 0 consumed)
+    // the next residue's first-phase operands fly under this residue's last phase
+    if (node + (int)gridDim.x < N) fetch_first(node + gridDim.x);
+    // ---- phase 3: dE (+)= W1b^T rows; dW1b += rows (x) e
+    f32x4 d[KT];
+    gemm(1, w1h, w1l, d);
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      f32x4 v = d[c] * un2;
+      if (accumulate) v += pe[c];
+      __builtin_nontemporal_store(v, &dE[off + (wave * KT + c) * 64]);
+    }
+    contract(1, accW1);
+  }
+  // this workgroup's partial sums: [dW2 | db2] and [dW1b | -]
+  float* P = part + (size_t)blockIdx.x * 2 * WG_PART;
+#pragma unroll
+  for (int j = 0; j < MPNN_NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      P[(16 * wave + 4 * g + r) * MPNN_H + 16 * j + col] = accW2[j][r] * un1;
+      P[WG_PART + (16 * wave + 4 * g + r) * MPNN_H + 16 * j + col] = accW1[j][r] * un2;
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v = column_sum(bacc[r]);
+    if (col == 0) {
+      P[MPNN_H * MPNN_H + 16 * wave + 4 * g + r] = v;
+      P[WG_PART + MPNN_H * MPNN_H + 16 * wave + 4 * g + r] = 0.f;
+    }
   }
 }
 
@@ -623,6 +858,48 @@ extern "C" int mpnn_message_bwd(int dec, const float* dgsum, const float* a1_fra
   MPNN_LAUNCH_CHECK();
 }
 
+extern "C" int mpnn_message_bwd_fused(int dec, const float* dgsum, const float* a1_frag, const float* a2_frag,
+                                     const float* hE_frag, const int32_t* E_idx32, const float* mask,
+                                     const float* edge_mask, const float* W2T_packed, const float* W1bT_packed, int B,
+                                     int L, int K, float* da1_rows, float* dP, float* dE_frag, int accumulate,
+                                     int w_valid, float* dW2, float* db2, float* dW1b, float* workspace,
+                                     int workspace_floats, void* stream) {
+  MPNN_CHECK_ARG(dgsum && a1_frag && a2_frag && hE_frag && E_idx32 && mask && W2T_packed && W1bT_packed && da1_rows &&
+                     dP && dE_frag && dW2 && db2 && dW1b && workspace,
+                 "mpnn_message_bwd_fused: null pointer");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 48, "mpnn_message_bwd_fused: bad sizes (K <= 48; above: mpnn_message_bwd)");
+  MPNN_CHECK_ARG(!w_valid || (dec && edge_mask), "mpnn_message_bwd_fused: w_valid is the decoder's form and needs edge_mask");
+  const int N = B * L, KT = (K + 15) / 16;
+  int nwg = edge_grid(N, 1);
+  if (nwg > (workspace_floats - 64) / (2 * WG_PART)) nwg = (workspace_floats - 64) / (2 * WG_PART);
+  MPNN_CHECK_ARG(nwg >= 1, "mpnn_message_bwd_fused: workspace holds no partial (64 + 33024 floats per workgroup, one per CU)");
+  unsigned* scales = reinterpret_cast<unsigned*>(workspace);
+  workspace += 64;
+  dim3 grid(nwg), block(FB_WAVES * 64);
+  hipStream_t st = (hipStream_t)stream;
+#define MPNN_FB_LAUNCH(kt, DECV)                                                                                     \
+  hipLaunchKernelGGL((k_message_bwd_fused<kt, DECV>), grid, block, 0, st, dgsum, (const f32x4*)a1_frag,               \
+                     (const f32x4*)a2_frag, (const f32x4*)hE_frag, E_idx32, mask, edge_mask, (const h8*)W2T_packed,  \
+                     (const h8*)W1bT_packed, N, L, K, da1_rows, dP, (f32x4*)dE_frag, accumulate, w_valid, scales, workspace)
+  if (hipMemsetAsync(scales, 0, 2 * sizeof(unsigned), st) != hipSuccess) {
+    mpnn_set_error("mpnn_message_bwd_fused: hipMemsetAsync failed");
+    return 1;
+  }
+  hipLaunchKernelGGL(k_fused_scales, dim3(64), dim3(256), 0, st, dgsum, (size_t)N * MPNN_H, (const h8*)W2T_packed,
+                     scales);
+  if (dec) {
+    if (KT == 1) MPNN_FB_LAUNCH(1, true); else if (KT == 2) MPNN_FB_LAUNCH(2, true); else MPNN_FB_LAUNCH(3, true);
+  } else {
+    if (KT == 1) MPNN_FB_LAUNCH(1, false); else if (KT == 2) MPNN_FB_LAUNCH(2, false); else MPNN_FB_LAUNCH(3, false);
+  }
+#undef MPNN_FB_LAUNCH
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((WG_PART + 15) / 16), dim3(256), 0, st, workspace, nwg, (size_t)(2 * WG_PART),
+                     dW2, db2);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((WG_PART + 15) / 16), dim3(256), 0, st, workspace + WG_PART, nwg,
+                     (size_t)(2 * WG_PART), dW1b, (float*)nullptr);
+  MPNN_LAUNCH_CHECK();
+}
+
 extern "C" int mpnn_enc_edge_update_bwd(const float* dy_frag, const float* z_frag, const float* a2_frag,
                                         const float* a1_frag, const float* ln_w, const float* W13T_packed,
                                         const float* W12T_packed, const float* W11bT_packed, int B, int L, int K,
@@ -682,7 +959,8 @@ extern "C" int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax
     if (b_gelu) MPNN_WGRAD_LAUNCH(false, true); else MPNN_WGRAD_LAUNCH(false, false);
   }
 #undef MPNN_WGRAD_LAUNCH
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((WG_PART + 15) / 16), dim3(256), 0, st, workspace, nwg, dW, dbias);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((WG_PART + 15) / 16), dim3(256), 0, st, workspace, nwg, (size_t)WG_PART, dW,
+                     dbias);
   MPNN_LAUNCH_CHECK();
 }
 

@@ -656,16 +656,20 @@ def _forward_shared(model, X, S, mask, chain_M, residue_idx, chain_encoding_all,
 # ---------------------------------------------------------------------------
 # autoregressive sampling (BASELINE configs[4]; no reference function, contract in include/mpnn_hip.h)
 # ---------------------------------------------------------------------------
-def _encode(model, X, mask, residue_idx, chain_labels, backbone_noise):
+def _encode(model, X, mask, residue_idx, chain_labels, backbone_noise, geometry=None):
     """Featurizer + encoder stack (reference :441-470) -> dict(hE, hV, PQ, K, E_idx64, E_idx32, edge_mask).
-    PQ's trailing blocks are Pa_0 | A_0 (WITHOUT the sequence term) | PVenc_0 | PVenc_1 | ..."""
+    PQ's trailing blocks are Pa_0 | A_0 (WITHOUT the sequence term) | PVenc_0 | PVenc_1 | ...
+    geometry: the result of _geometry when the caller has already run the neighbour search (sampling does, to
+    schedule its levels beside the encoder)."""
     dev = X.device
     B, L = mask.shape
     N = B * L
     pw = packed(model)
     st = stream_ptr()
     fm = model.features
-    atoms, _, E_idx64, E_idx32, _, edge_mask, K = _geometry(fm, X, mask, backbone_noise, model.training)
+    if geometry is None:
+        geometry = _geometry(fm, X, mask, backbone_noise, model.training)
+    atoms, _, E_idx64, E_idx32, _, edge_mask, K = geometry
     occ = _occupancy(fm, atoms, mask, B, L)
     hE, _ = _edge_features(pw, atoms, E_idx32, residue_idx, chain_labels, B, L, K, False)
     hV = torch.zeros(N, H, device=dev, dtype=torch.float32)
@@ -705,10 +709,26 @@ def decode_levels(order, rank, E_idx32, n_rows, enc_rows, L, K):
     """Dependency level of every residue of every sample (mpnn_decode_levels): residues of one level only read
     finished residues, so a level is one batched launch.
     -> (residue ids sorted by level [n_rows*L] int32, residues per level: list of int)."""
+    perm, level = _decode_levels_async(order, rank, E_idx32, n_rows, enc_rows, L, K)
+    return perm, torch.bincount(level)[1:].tolist()
+
+
+def _decode_levels_async(order, rank, E_idx32, n_rows, enc_rows, L, K):
+    """The device part of decode_levels (no host read): -> (perm, level)."""
     level = torch.empty(n_rows * L, device=order.device, dtype=torch.int32)
     call("mpnn_decode_levels", ptr(order), ptr(rank), ptr(E_idx32), n_rows, enc_rows, L, K, ptr(level), stream_ptr())
     perm = torch.argsort(level, stable=True).to(torch.int32)
-    return perm, torch.bincount(level)[1:].tolist()
+    return perm, level
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    s = _SIDE_STREAMS.get(dev)
+    if s is None:
+        s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return s
 
 
 def sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true=None, n_samples=1, temperature=0.1,
@@ -743,10 +763,16 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
         raise ValueError("mpnn_amd.sample needs 1..4 decoder layers")
     st = stream_ptr()
     with torch.no_grad():
-        enc = _encode(model, X, mask, _i64(residue_idx), _i64(chain_encoding_all), backbone_noise)
-        K = enc["K"]
+        # The level schedule depends on the neighbour lists and the decoding orders only, and the host must read the
+        # level sizes before it can issue the level loop.  So: neighbour search first; orders, ranks, levels and their
+        # sort on a SIDE stream while the main stream runs edge features and the encoder; the one host read of the call
+        # waits for the side stream only - the encoder is already enqueued and keeps the GPU busy meanwhile.
+        geometry = _geometry(model.features, X, mask, backbone_noise, model.training)
+        K = geometry[6]
         if K > 64:
             raise NotImplementedError("mpnn_amd.sample covers k_neighbors <= 64")
+        main = torch.cuda.current_stream()
+        side = _side_stream(dev)
         Ns = n_samples * N
         cm = (_f32(chain_M) * mask)
         if fix_order is not None:
@@ -763,9 +789,16 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
             g_.manual_seed(int(seed))
             noise = torch.randn(n_samples, B, L, device=dev, generator=g_)
             order = torch.argsort((cm.unsqueeze(0) + 0.0001) * torch.abs(noise), dim=-1)
-        rank = torch.zeros(Ns, device=dev, dtype=torch.int32)
-        call("mpnn_order_rank", ptr(order), n_samples * B, L, ptr(rank), st)
-        perm, counts = decode_levels(order, rank, enc["E_idx32"], n_samples * B, B, L, K)
+        geo_done = torch.cuda.Event()
+        geo_done.record(main)          # the orders and the neighbour lists were produced on the main stream
+        side.wait_event(geo_done)
+        with torch.cuda.stream(side):
+            rank = torch.zeros(Ns, device=dev, dtype=torch.int32)
+            call("mpnn_order_rank", ptr(order), n_samples * B, L, ptr(rank), stream_ptr())
+            perm, level = _decode_levels_async(order, rank, geometry[3], n_samples * B, B, L, K)
+        enc = _encode(model, X, mask, _i64(residue_idx), _i64(chain_encoding_all), backbone_noise, geometry=geometry)
+        for t in (rank, perm, level):
+            t.record_stream(main)      # allocated on the side stream, used on the main one from here on
 
         S_in = _i64(S_true).reshape(1, N).expand(n_samples, N).contiguous() if S_true is not None else \
             torch.zeros(n_samples, N, device=dev, dtype=torch.int64)
@@ -838,24 +871,29 @@ def _sample(model, X, mask, chain_M, residue_idx, chain_encoding_all, S_true, n_
             f_msg = lambda *a: (call("mpnn_dec_message_subset", *a), 0)[1]
             f_node = lambda *a: (call("mpnn_node_update_subset", *a), 0)[1]
             f_head = lambda *a: (call("mpnn_sample_subset", *a), 0)[1]
+        layers = (_lib.LevelLayer * n_dec)()
+        for l, lw in enumerate(pw.dec):
+            grp = pw.g_dec[l]
+            y = layers[l]
+            y.P, y.ldp, y.offP = ptr(PA[l]), 2 * H, 0
+            y.RowA, y.lda, y.offA = ptr(PA[l]), 2 * H, H
+            y.offEnc = base + 2 * H + H * l
+            y.W1b_packed, y.W2_packed, y.b2 = ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"])
+            y.hV_in, y.hV_out = ptr(hVs[l]), ptr(hVs[l + 1])
+            y.W3_packed, y.b3, y.ln1_w, y.ln1_b = ptr(lw["W3"]), ptr(lw["b3"]), ptr(lw["ln1w"]), ptr(lw["ln1b"])
+            y.Win_packed, y.b_in, y.Wout8_packed, y.b_out = ptr(lw["Win"]), ptr(lw["bin"]), ptr(lw["Wout8"]), ptr(lw["bout"])
+            y.ln2_w, y.ln2_b, y.scale = ptr(lw["ln2w"]), ptr(lw["ln2b"]), lw["scale"]
+            y.Wproj_packed, y.bproj, y.nproj = ptr(grp[0]), ptr(grp[1]), grp[2]
+            y.PQ = ptr(PA[l + 1]) if grp[2] else None
+        # everything above (state tensors, argument lists) was prepared without knowing the level sizes; now the call's
+        # one host read, which waits for the side stream only
+        with torch.cuda.stream(side):
+            counts = torch.bincount(level)[1:].tolist()
+        main.wait_stream(side)
         list_ptr = perm.data_ptr()
         start = 0
         rc = 0
         if run_in_c and mode == "layer" and plans[-1][2][37] == 0:
-            layers = (_lib.LevelLayer * n_dec)()
-            for l, lw in enumerate(pw.dec):
-                grp = pw.g_dec[l]
-                y = layers[l]
-                y.P, y.ldp, y.offP = ptr(PA[l]), 2 * H, 0
-                y.RowA, y.lda, y.offA = ptr(PA[l]), 2 * H, H
-                y.offEnc = base + 2 * H + H * l
-                y.W1b_packed, y.W2_packed, y.b2 = ptr(lw["W1b"]), ptr(lw["W2"]), ptr(lw["b2"])
-                y.hV_in, y.hV_out = ptr(hVs[l]), ptr(hVs[l + 1])
-                y.W3_packed, y.b3, y.ln1_w, y.ln1_b = ptr(lw["W3"]), ptr(lw["b3"]), ptr(lw["ln1w"]), ptr(lw["ln1b"])
-                y.Win_packed, y.b_in, y.Wout8_packed, y.b_out = ptr(lw["Win"]), ptr(lw["bin"]), ptr(lw["Wout8"]), ptr(lw["bout"])
-                y.ln2_w, y.ln2_b, y.scale = ptr(lw["ln2w"]), ptr(lw["ln2b"]), lw["scale"]
-                y.Wproj_packed, y.bproj, y.nproj = ptr(grp[0]), ptr(grp[1]), grp[2]
-                y.PQ = ptr(PA[l + 1]) if grp[2] else None
             c_counts = (ctypes.c_int * len(counts))(*counts)
             call("mpnn_decode_run", ptr(enc["hE"]), ptr(PQenc), PQenc.shape[1], ptr(rank), ptr(enc["E_idx32"]),
                  ptr(mask_s), ptr(enc["edge_mask"]), list_ptr, c_counts, len(counts), N, L, K, float(K), layers, n_dec,

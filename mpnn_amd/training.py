@@ -17,6 +17,8 @@ There is no CPU path: every tensor must live on the ROCm device.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.amp import custom_bwd, custom_fwd  # backward runs under the forward's autocast state (off: modules.forward)
@@ -129,6 +131,10 @@ def _pack_blocks(blocks):
     return [out[i * 16384:(i + 1) * 16384] for i in range(n)]
 
 
+# mpnn_message_bwd_fused (K <= 48) instead of mpnn_message_bwd + 2 x mpnn_edge_wgrad
+FUSED_MSG_BWD = os.environ.get("MPNN_FUSED_MSG_BWD", "1") != "0"
+
+
 def _wgrad(A, a_rows, amax, Bfrag, b_gelu, g, want_bias):
     dW = _zeros(A.device, H, H)
     db = _zeros(A.device, H) if want_bias else None
@@ -188,6 +194,7 @@ def _workspace(dev, n_rows=0):
     stream reuse it in order).  n_rows: rows (residues) of the call, for the entry points whose need grows with them."""
     lib = _lib.load()
     need = max(lib.mpnn_workspace_bytes(b"mpnn_edge_wgrad", 1 << 30, 1),
+               lib.mpnn_workspace_bytes(b"mpnn_message_bwd_fused", 0, 0),
                lib.mpnn_workspace_bytes(b"mpnn_enc_edge_update_bwd", 0, 0),
                lib.mpnn_workspace_bytes(b"mpnn_logits_log_softmax_bwd", int(n_rows), 0),
                lib.mpnn_workspace_bytes(b"mpnn_node_update_bwd", int(n_rows), 0)) // 4
@@ -327,7 +334,6 @@ class MessageFn(torch.autograd.Function):
         hE, a1, a2, W1b, W2 = ctx.saved_tensors
         dev = hE.device
         dgsum = dgsum.contiguous()
-        da2 = torch.empty_like(a1)
         rows = torch.empty(g.N * g.Kp, H, device=dev, dtype=torch.float32)
         dP = torch.empty(g.N, H, device=dev, dtype=torch.float32)
         slot = ctx.slot
@@ -336,6 +342,16 @@ class MessageFn(torch.autograd.Function):
             slot.buf = torch.empty_like(a1)
         dE = slot.buf
         w2t, w1t = _pack_blocks([(W2, True), (W1b, True)])
+        if FUSED_MSG_BWD and g.K <= 48:
+            # one kernel: chain + both weight-gradient contractions (da2 never exists in memory)
+            dW2, db2, dW1b = _zeros(dev, H, H), _zeros(dev, H), _zeros(dev, H, H)
+            ws = _workspace(dev)
+            call("mpnn_message_bwd_fused", int(dec), ptr(dgsum), ptr(a1), ptr(a2), ptr(hE), ptr(g.E_idx32), ptr(g.mask),
+                 ptr(g.edge_mask), ptr(w2t), ptr(w1t), g.B, g.L, g.K, ptr(rows), ptr(dP), ptr(dE), 0 if first else 1,
+                 ctx.w_valid, ptr(dW2), ptr(db2), ptr(dW1b), ptr(ws), ws.numel(), stream_ptr())
+            dRowA, dRowB = _gather(rows, g, g.sel if dec else None)
+            return None, None, None, dE if first else None, dP, dRowA, dRowB, dW1b, dW2, db2
+        da2 = torch.empty_like(a1)
         amax = _zeros(dev, 2)
         call("mpnn_message_bwd", int(dec), ptr(dgsum), ptr(a1), ptr(a2), ptr(g.E_idx32), ptr(g.mask), ptr(g.edge_mask),
              ptr(w2t), ptr(w1t), g.B, g.L, g.K, ptr(da2), ptr(rows),
