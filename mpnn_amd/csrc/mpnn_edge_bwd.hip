@@ -525,11 +525,17 @@ k_wgrad_reduce(const float* __restrict__ part, int nparts, size_t stride, float*
 //   Bf  [k-step][column tile][hi | lo][lane]   the B fragments of the next GEMM (k = features: every wave needs all),
 //   sA / sB [hi | lo][feature][edge]           f16 planes with the EDGES contiguous: the MFMA k dimension of the
 //                                              contractions dW[o][i] += sum_e A[e][o] B[e][i] (as in k_wgrad).
-// Per residue: da2 = gelu'(a2) dgsum w -> (barrier) -> dg1 = W2^T da2 | dW2 += da2 (x) gelu(a1) -> da1 = dg1 gelu'(a1),
-// dP, the s-scaled rows for the gather -> (barrier: largest |row|) -> (barrier) -> dE (+)= W1b^T rows |
-// dW1b += rows (x) e.  Gradient operands are scaled by an exact power of two before their f16 hi/lo split (da2: from
-// the bound 1.13 max |dgsum_i|, which every wave computes for itself; the rows: from their exact workgroup maximum).
-// Per-workgroup partial sums [2][128 x 128 + 128] go to the workspace; k_wgrad_reduce adds them in a fixed order.
+// Per residue: da2 = gelu'(a2) dgsum w -> (barrier A) -> dg1 = W2^T da2, da1 = dg1 gelu'(a1), dP, the s-scaled rows
+// for the gather | dW2 += da2 (x) gelu(a1) -> (barrier B) -> dE (+)= W1b^T rows | dW1b += rows (x) e.
+// REGISTERS decide this kernel: 132 hold the weights and accumulators, 48 the four operand tiles of a residue (each
+// re-requested for the NEXT residue right after its last use: a workgroup runs in lock-step, nothing else on the CU
+// covers an exposed round trip).  The first form spilled a hundred registers, and spill traffic (per-wave scratch:
+// 80 MB over the launch, far beyond L2) tripled the kernel's HBM bytes (rocprofv3 FETCH_SIZE 2.9 GB against 1.0 GB) -
+// every GEMM / contraction below therefore handles ONE column tile at a time with a fenced two-deep LDS read pipeline,
+// and global addresses are a scalar residue base plus a fixed 32-bit lane offset.
+// Gradient operands are scaled by an exact power of two before their f16 hi/lo split, launch-wide, from bounds
+// (k_fused_scales).  Per-workgroup partial sums [2][128 x 128 + 128] go to the workspace; k_wgrad_reduce adds them in a
+// fixed order.
 // ---------------------------------------------------------------------------
 constexpr int FB_WAVES = 8;
 constexpr int FB_LDK = 16 * 3 + 4;  // padded edge stride (halves) of the planes, as WG_LDK of k_wgrad at KTM = 3
@@ -579,14 +585,15 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
   const float sc1 = pow2_scale_from_bits((unsigned)__float_as_int(m1)), un1 = pow2_inverse(sc1);
   const float sc2 = pow2_scale_from_bits((unsigned)__float_as_int(m2)), un2 = pow2_inverse(sc2);
   // this wave's rows of the two transposed weights: the A fragments of its output tile, all k-steps
-  h8 w2h[NKK], w2l[NKK], w1h[NKK], w1l[NKK];
+  // (W2^T stays in registers; W1b^T's rows are re-requested from L2 for every residue behind the second phase's
+  // arithmetic and live through the third phase only: with both resident the K = 48 instance spilled 40 registers)
+  h8 w2h[NKK], w2l[NKK];
 #pragma unroll
   for (int kk = 0; kk < NKK; ++kk) {
     w2h[kk] = W2T[((wave * NKK + kk) * 2 + 0) * 64 + lane];
     w2l[kk] = W2T[((wave * NKK + kk) * 2 + 1) * 64 + lane];
-    w1h[kk] = W1bT[((wave * NKK + kk) * 2 + 0) * 64 + lane];
-    w1l[kk] = W1bT[((wave * NKK + kk) * 2 + 1) * 64 + lane];
   }
+  const h8* W1w = W1bT + (size_t)wave * NKK * 2 * 64 + lane;
   f32x4 accW2[MPNN_NT], accW1[MPNN_NT];
 #pragma unroll
   for (int j = 0; j < MPNN_NT; ++j) accW2[j] = accW1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -594,136 +601,206 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
   // where this lane's share of a (feature tile, column tile) goes in the planes / in a B fragment
   const int frow = 16 * wave + 4 * g + (col & 3);
   const int bf_kk = wave >> 1, bf_half = (wave & 1) * 4;  // halves [bf_half, bf_half + 4) of k-step bf_kk
+  const int G = gridDim.x;
 
   // the contraction of one stage: acc[j] += sum_e A[row block of this wave][e] B[tile j][e]  (scaled by the stage's sc)
   auto contract = [&](int st, f32x4 (&acc)[MPNN_NT]) {
+    // operands of one pair of output tiles at a time, the next pair's reads issued ahead of this pair's MFMAs (the
+    // fences keep hipcc from hoisting every LDS read of the stage to the top: 100 registers)
+    h4 bh[2][2], bl[2][2];
+    auto rd = [&](int buf, int c, int j0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bh[buf][u] = *reinterpret_cast<const h4*>(&sB[st][0][16 * (j0 + u) + col][16 * c + 4 * g]);
+        bl[buf][u] = *reinterpret_cast<const h4*>(&sB[st][1][16 * (j0 + u) + col][16 * c + 4 * g]);
+      }
+    };
+    rd(0, 0, 0);
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
       const h4 ah = *reinterpret_cast<const h4*>(&sA[st][0][16 * wave + col][16 * c + 4 * g]);
       const h4 al = *reinterpret_cast<const h4*>(&sA[st][1][16 * wave + col][16 * c + 4 * g]);
 #pragma unroll
-      for (int j = 0; j < MPNN_NT; ++j) {
-        const h4 bh = *reinterpret_cast<const h4*>(&sB[st][0][16 * j + col][16 * c + 4 * g]);
-        const h4 bl = *reinterpret_cast<const h4*>(&sB[st][1][16 * j + col][16 * c + 4 * g]);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc[j], 0, 0, 0);
+      for (int jp = 0; jp < MPNN_NT / 2; ++jp) {
+        const int cur = (c * (MPNN_NT / 2) + jp) & 1;
+        if (jp + 1 < MPNN_NT / 2) rd(cur ^ 1, c, 2 * (jp + 1));
+        else if (c + 1 < KT) rd(cur ^ 1, c + 1, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int j = 2 * jp + u;
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh[cur][u], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl[cur][u], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh[cur][u], acc[j], 0, 0, 0);
+        }
+        FENCE();
       }
     }
   };
-  // this wave's tile of a gradient (already scaled) -> its halves of the next GEMM's B fragments and its plane rows
-  auto publish = [&](int st, const f32x4 (&x)[KT], const f32x4 (&bsrc)[KT], bool b_gelu) {
-#pragma unroll
-    for (int c = 0; c < KT; ++c) {
-      h4 hh, ll;
-      split4(x[c], hh, ll);
-      _Float16* bh = reinterpret_cast<_Float16*>(&Bf[st][bf_kk][c][0][lane]) + bf_half;
-      _Float16* bl = reinterpret_cast<_Float16*>(&Bf[st][bf_kk][c][1][lane]) + bf_half;
-      *reinterpret_cast<h4*>(bh) = hh;
-      *reinterpret_cast<h4*>(bl) = ll;
-      const int ecol = 16 * c + 4 * (col >> 2);
-      split4(quad_transpose(x[c]), hh, ll);
-      *reinterpret_cast<h4*>(&sA[st][0][frow][ecol]) = hh;
-      *reinterpret_cast<h4*>(&sA[st][1][frow][ecol]) = ll;
-      split4(quad_transpose(b_gelu ? gelu4(bsrc[c]) : bsrc[c]), hh, ll);
-      *reinterpret_cast<h4*>(&sB[st][0][frow][ecol]) = hh;
-      *reinterpret_cast<h4*>(&sB[st][1][frow][ecol]) = ll;
-    }
+  // one column tile of this wave's gradient tile (already scaled) -> its halves of the next GEMM's B fragments and its
+  // A-plane rows
+  auto publish_grad = [&](int st, int c, const f32x4 x) {
+    h4 hh, ll;
+    split4(x, hh, ll);
+    _Float16* bh = reinterpret_cast<_Float16*>(&Bf[st][bf_kk][c][0][lane]) + bf_half;
+    _Float16* bl = reinterpret_cast<_Float16*>(&Bf[st][bf_kk][c][1][lane]) + bf_half;
+    *reinterpret_cast<h4*>(bh) = hh;
+    *reinterpret_cast<h4*>(bl) = ll;
+    split4(quad_transpose(x), hh, ll);
+    const int ecol = 16 * c + 4 * (col >> 2);
+    *reinterpret_cast<h4*>(&sA[st][0][frow][ecol]) = hh;
+    *reinterpret_cast<h4*>(&sA[st][1][frow][ecol]) = ll;
   };
-  // y[c] = sum_k W^T[tile of this wave][k] X[k][column tile c], X from the B fragments of stage st
-  auto gemm = [&](int st, const h8 (&wh)[NKK], const h8 (&wl)[NKK], f32x4 (&y)[KT]) {
+  // one column tile of a contraction's second operand -> its B-plane rows
+  auto publish_act = [&](int st, int c, const f32x4 v) {
+    h4 hh, ll;
+    split4(quad_transpose(v), hh, ll);
+    const int ecol = 16 * c + 4 * (col >> 2);
+    *reinterpret_cast<h4*>(&sB[st][0][frow][ecol]) = hh;
+    *reinterpret_cast<h4*>(&sB[st][1][frow][ecol]) = ll;
+  };
+  // y = sum_k W^T[tile of this wave][k] X[k][column tile c], X from the B fragments of stage st; the next k-step's
+  // fragment is read ahead of this one's MFMAs
+  auto gemm_tile = [&](int st, int c, const h8 (&wh)[NKK], const h8 (&wl)[NKK]) {
+    f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
+    BFrag b[2];
+    b[0].hi = Bf[st][0][c][0][lane];
+    b[0].lo = Bf[st][0][c][1][lane];
 #pragma unroll
-    for (int c = 0; c < KT; ++c) y[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < NKK; ++kk)
-#pragma unroll
-      for (int c = 0; c < KT; ++c) {
-        BFrag b;
-        b.hi = Bf[st][kk][c][0][lane];
-        b.lo = Bf[st][kk][c][1][lane];
-        y[c] = mfma_split(wh[kk], wl[kk], b, y[c]);
+    for (int kk = 0; kk < NKK; ++kk) {
+      if (kk + 1 < NKK) {
+        b[(kk + 1) & 1].hi = Bf[st][kk + 1][c][0][lane];
+        b[(kk + 1) & 1].lo = Bf[st][kk + 1][c][1][lane];
       }
+      y = mfma_split(wh[kk], wl[kk], b[kk & 1], y);
+      FENCE();
+    }
+    return y;
   };
-
-  // loads of one residue that its FIRST phase needs; issued one residue ahead
-  f32x4 x2[KT], x1[KT], gs;
+  // addresses = a uniform residue base (scalar registers) + a 32-bit lane offset that never changes
+  const unsigned tile_off = (unsigned)(wave * KT) * 64u + (unsigned)lane;  // f32x4 elements into a residue's fragments
+  auto tile_of = [&](const f32x4* base, int node) {
+    return base + (size_t)__builtin_amdgcn_readfirstlane(node) * (MPNN_NT * KT * 64);
+  };
+  auto load_tile = [&](f32x4 (&dst)[KT], const f32x4* base, int node) {
+    const f32x4* p = tile_of(base, node);
+#pragma unroll
+    for (int c = 0; c < KT; ++c) dst[c] = __builtin_nontemporal_load(&p[tile_off + (unsigned)c * 64u]);
+  };
+  f32x4 x2[KT], x1[KT], xe[KT], pe[KT], gs;
   float s[KT], w[KT];
-  auto fetch_first = [&](int node) {
+  // branch-free mask reads: out-of-range slots re-read slot K - 1 and are zeroed by the select
+  const float* em_base = edge_mask ? edge_mask : mask;  // (any readable address when there is no edge mask)
+  const bool has_em = edge_mask != nullptr;
+  auto load_masks = [&](int node_) {
+    const int node = __builtin_amdgcn_readfirstlane(node_);
     const int b = node / L;
     const float mi = mask[node];
+    const float* em_row = em_base + (has_em ? (size_t)node * K : (size_t)0);
+    const int* e_row = E_idx + (size_t)node * Kp;
+    const float* m_row = mask + (size_t)b * L;
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
       const int e = 16 * c + col;
-      float em = 1.0f;
-      if (edge_mask && e < K) em = edge_mask[(size_t)node * K + e];
+      const bool in = e < K;
+      const unsigned ec = (unsigned)(in ? e : K - 1);
+      const float em = has_em ? em_row[ec] : 1.0f;
       if (DEC) {
         s[c] = mi * em;
-        w[c] = e < K ? (w_valid ? em : 1.0f) : 0.0f;
+        w[c] = in ? (w_valid ? em : 1.0f) : 0.0f;
       } else {
         s[c] = 1.0f;
-        w[c] = e < K ? mi * mask[b * L + E_idx[(size_t)node * Kp + e]] * em : 0.0f;
+        const float mj = m_row[(unsigned)e_row[(unsigned)e]];
+        w[c] = in ? mi * mj * em : 0.0f;
       }
     }
-    const size_t off = (size_t)node * (MPNN_NT * KT * 64) + lane;
-#pragma unroll
-    for (int c = 0; c < KT; ++c) {
-      x2[c] = __builtin_nontemporal_load(&a2[off + (wave * KT + c) * 64]);
-      x1[c] = __builtin_nontemporal_load(&a1[off + (wave * KT + c) * 64]);
-    }
-    gs = *reinterpret_cast<const f32x4*>(dgsum + (size_t)node * MPNN_H + 16 * wave + 4 * g);
   };
+  auto load_gs = [&](int node) {
+    const float* p = dgsum + (size_t)__builtin_amdgcn_readfirstlane(node) * MPNN_H;
+    gs = *reinterpret_cast<const f32x4*>(&p[(unsigned)(16 * wave + 4 * g)]);
+  };
+  const unsigned row_off = (unsigned)col * MPNN_H + (unsigned)(16 * wave + 4 * g);  // into a residue's da1 rows
 
+  // Operand tiles are requested about two phases ahead of their use and are NOT kept live all the way round the loop
+  // (a ring one residue deep for each of the four tensors is 48 registers at every point; this is ~36):
+  //   a2, dgsum, a1, masks of the next residue: top of phase 3    (used in its phases 1 / 1+2)
+  //   e:                                        top of phase 1    (used in phase 2)
+  //   dE (accumulate):                          top of phase 2    (used in phase 3)
   int node = blockIdx.x;
-  if (node < N) fetch_first(node);
-  for (; node < N; node += gridDim.x) {
-    const size_t off = (size_t)node * (MPNN_NT * KT * 64) + lane;
+  if (node < N) {
+    load_masks(node);
+    load_tile(x2, a2, node);
+    load_gs(node);
+    load_tile(x1, a1, node);
+  }
+  for (; node < N; node += G) {
+    const int nxt = node + G;
+    const bool more = nxt < N;
+    load_tile(xe, hE, node);
+    FENCE();
     // ---- phase 1: da2 of this wave's feature tile; its B fragments and planes, the planes of gelu(a1)
-    f32x4 d2[KT];
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
-      d2[c] = gelu_grad4(x2[c]) * (gs * w[c]);
-      bacc += d2[c];
-      d2[c] *= sc1;
+      f32x4 d2 = gelu_grad4(x2[c]) * (gs * w[c]);
+      bacc += d2;
+      publish_grad(0, c, d2 * sc1);
+      publish_act(0, c, gelu4(x1[c]));
+      FENCE();
     }
-    publish(0, d2, x1, true);
-    // the second phase's operands of THIS residue (needed one barrier from now)
-    f32x4 xe[KT];
-#pragma unroll
-    for (int c = 0; c < KT; ++c) xe[c] = __builtin_nontemporal_load(&hE[off + (wave * KT + c) * 64]);
     __syncthreads();  // A: stage-0 fragments and planes complete (and stage 1 of the previous residue consumed)
-    // ---- phase 2: dg1 = W2^T da2; dW2 += da2 (x) gelu(a1); da1, dP, rows
-    f32x4 y[KT];
-    gemm(0, w2h, w2l, y);
+    if (accumulate) load_tile(pe, dE, node);
+    FENCE();
+    // ---- phase 2: dg1 = W2^T da2; da1, dP, rows; dW2 += da2 (x) gelu(a1)
     f32x4 ps = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
-      y[c] *= gelu_grad4(x1[c]) * un1;
-      ps += y[c];
-      if (DEC) y[c] *= s[c];
-      __builtin_nontemporal_store(y[c], reinterpret_cast<f32x4*>(da1_nat + ((size_t)node * Kp + 16 * c + col) * MPNN_H +
-                                                                  16 * wave + 4 * g));
-      y[c] *= sc2;
+      f32x4 y = gemm_tile(0, c, w2h, w2l);
+      y *= gelu_grad4(x1[c]) * un1;
+      ps += y;
+      if (DEC) y *= s[c];
+      {
+        float* rb = da1_nat + (size_t)__builtin_amdgcn_readfirstlane(node) * (Kp * MPNN_H);
+        __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(&rb[row_off + (unsigned)(16 * c) * MPNN_H]));
+      }
+      publish_grad(1, c, y * sc2);
+      publish_act(1, c, xe[c]);
+      FENCE();
     }
     ps = column_sum4(ps);
-    if (col == 0) *reinterpret_cast<f32x4*>(dP + (size_t)node * MPNN_H + 16 * wave + 4 * g) = ps;
-    publish(1, y, xe, false);
-    contract(0, accW2);
-    f32x4 pe[KT];
-    if (accumulate) {
-#pragma unroll
-      for (int c = 0; c < KT; ++c) pe[c] = dE[off + (wave * KT + c) * 64];
+    if (col == 0) {
+      float* pb = dP + (size_t)__builtin_amdgcn_readfirstlane(node) * MPNN_H;
+      *reinterpret_cast<f32x4*>(&pb[(unsigned)(16 * wave + 4 * g)]) = ps;
     }
-    __syncthreads();  // B: stage-1 fragments and planes complete (and stage 0 consumed)
-    // the next residue's first-phase operands fly under this residue's last phase
-    if (node + (int)gridDim.x < N) fetch_first(node + gridDim.x);
-    // ---- phase 3: dE (+)= W1b^T rows; dW1b += rows (x) e
-    f32x4 d[KT];
-    gemm(1, w1h, w1l, d);
+    FENCE();
+    h8 w1h[NKK], w1l[NKK];
+    {
+      auto Wp = GLOBAL(W1w);
+      LAUNDER(Wp);
 #pragma unroll
-    for (int c = 0; c < KT; ++c) {
-      f32x4 v = d[c] * un2;
-      if (accumulate) v += pe[c];
-      __builtin_nontemporal_store(v, &dE[off + (wave * KT + c) * 64]);
+      for (int kk = 0; kk < NKK; ++kk) {
+        w1h[kk] = Wp[(kk * 2 + 0) * 64];
+        w1l[kk] = Wp[(kk * 2 + 1) * 64];
+      }
+    }
+    FENCE();
+    contract(0, accW2);
+    __syncthreads();  // B: stage-1 fragments and planes complete (and stage 0 consumed)
+    if (more) {
+      load_masks(nxt);
+      load_tile(x2, a2, nxt);
+      load_gs(nxt);
+      load_tile(x1, a1, nxt);
+    }
+    FENCE();
+    // ---- phase 3: dE (+)= W1b^T rows; dW1b += rows (x) e
+    {
+      f32x4* dst = const_cast<f32x4*>(tile_of(dE, node));
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        f32x4 v = gemm_tile(1, c, w1h, w1l) * un2;
+        if (accumulate) v += pe[c];
+        __builtin_nontemporal_store(v, &dst[tile_off + (unsigned)c * 64u]);
+        FENCE();
+      }
     }
     contract(1, accW1);
   }
