@@ -273,12 +273,14 @@ int mpnn_message_train(int dec, const float* hE_frag, const float* P, const floa
 /* Forward of mpnn_enc_edge_update, out of place, storing a1', a2' and the pre-LayerNorm sum z (:90-95).
  * p_drop > 0 applies EncLayer.dropout3 (:94) to the MLP output: an element is kept when
  * mix32(element_index * 0x9E3779B1 ^ drop_seed) >= p_drop * 2^32 (element_index = its float index in the fragment
- * array) and scaled by 1 / (1 - p_drop); the backward call must be given the same p_drop and drop_seed. */
+ * array) and scaled by 1 / (1 - p_drop); the backward call must be given the same p_drop and drop_seed.
+ * rstd_max (one float, zero it first; may be NULL): receives the largest 1 / sqrt(var + eps) of the launch's
+ * LayerNorms, which mpnn_enc_edge_update_bwd_fused needs for its operand scales. */
 int mpnn_enc_edge_update_train(const float* hE_frag, const float* P, const float* Q, const int32_t* E_idx32,
                                const float* W11b_packed, const float* W12_packed, const float* b12,
                                const float* W13_packed, const float* b13, const float* ln_w, const float* ln_b, int B,
                                int L, int K, float* hE_out, float* a1_frag, float* a2_frag, float* z_frag,
-                               float p_drop, uint32_t drop_seed, void* stream);
+                               float p_drop, uint32_t drop_seed, float* rstd_max, void* stream);
 
 /* Backward of the message MLP: given dgsum, writes da2 (fragment), s-scaled da1 rows, dP = sum_k da1, and
  * dE (+)= W1b^T (s da1).  W2T / W1bT are mpnn_pack_linear_split of the TRANSPOSED matrices.
@@ -295,13 +297,35 @@ int mpnn_message_bwd(int dec, const float* dgsum, const float* a1_frag, const fl
  * whose eager form materialises every one of these tensors).  dW2 / db2 / dW1b are ACCUMULATED INTO (zero them for a
  * plain gradient).  The f16 hi/lo operand splits use launch-wide power-of-two scales from bounds (1.13 max |dgsum|,
  * times max_k sum_o |W2[o][k]| for the rows), found by a small pre-launch: no host value is needed.
+ * dE_absmax (one float, zero it before the FIRST writer of a dE buffer; may be NULL): atomic max of |dE| as written.
  * workspace: 64 + 33024 floats per workgroup, one workgroup per CU at most (mpnn_workspace_bytes); partial sums are
  * added in a fixed order - bit-identical from run to run. */
 int mpnn_message_bwd_fused(int dec, const float* dgsum, const float* a1_frag, const float* a2_frag,
                            const float* hE_frag, const int32_t* E_idx32, const float* mask, const float* edge_mask,
                            const float* W2T_packed, const float* W1bT_packed, int B, int L, int K, float* da1_rows,
                            float* dP, float* dE_frag, int accumulate, int w_valid, float* dW2, float* db2, float* dW1b,
-                           float* workspace, int workspace_floats, void* stream);
+                           float* dE_absmax, float* workspace, int workspace_floats, void* stream);
+
+/* mpnn_enc_edge_update_bwd AND the weight-gradient contractions of W13 and W12 (dW13 += dzd (x) gelu(a2),
+ * db13 += sum dzd, dW12 += da2 (x) gelu(a1), db12 += sum da2) in one kernel, for K <= 48 (above:
+ * mpnn_enc_edge_update_bwd + 3 x mpnn_edge_wgrad): dz and da2 are never written, a2 / a1 are read once (reference: the
+ * autograd of EncLayer's edge update, model_utils.py:90-95, whose eager form materialises every one of these tensors).
+ * What remains for the caller: dW11b = mpnn_edge_wgrad(da1_rows, hE) with da1_absmax as its A_absmax.
+ * dE_frag must NOT alias dy_frag.  dW13 / db13 / dW12 / db12 / dln are ACCUMULATED INTO (zero them for a plain gradient).
+ * Operand scales (f16 hi/lo splits of gradient-sized values) are launch-wide powers of two from BOUNDS:
+ *   |dz| <= 13.3 * rstd_max * max |ln_w| * dy_absmax / (1 - p_drop), then 1.13 * max_k sum_o |W[o][k]| per GEMM;
+ * dy_absmax (one float on the device: max |dy| or any upper bound of it - the dE_absmax output of the kernels that
+ * wrote dy) and rstd_max (mpnn_enc_edge_update_train's output) are read by a small pre-launch: no host value is needed.
+ * da1_absmax, dE_absmax (one float each, zero them first; dE_absmax may be NULL) receive max |da1 rows| and max |dE|.
+ * workspace: 64 + 33280 floats per workgroup, one workgroup per CU at most (mpnn_workspace_bytes); partial sums are
+ * added in a fixed order - bit-identical from run to run. */
+int mpnn_enc_edge_update_bwd_fused(const float* dy_frag, const float* z_frag, const float* a2_frag,
+                                   const float* a1_frag, const float* ln_w, const float* W13T_packed,
+                                   const float* W12T_packed, const float* W11bT_packed, int B, int L, int K,
+                                   float* da1_rows, float* da1_absmax, float* dP, float* dE_frag, float* dln,
+                                   float* dW13, float* db13, float* dW12, float* db12, const float* dy_absmax,
+                                   const float* rstd_max, float* dE_absmax, float p_drop, uint32_t drop_seed,
+                                   float* workspace, int workspace_floats, void* stream);
 
 /* Backward of the edge update: LayerNorm', W13^T, W12^T, W11b^T; dln[0:128] += d ln_w, dln[128:256] += d ln_b.
  * dE_frag may alias dy_frag.  amax3[0..2] (zero them first) receive max |dz|, |da2|, |da1 rows|.

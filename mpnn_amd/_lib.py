@@ -58,9 +58,10 @@ SIGNATURES = {
     "mpnn_logits_log_softmax": [_P, _P, _P, _I, _I, _P, _P],
     # training step (forward with saved pre-activations, backward, weight gradients)
     "mpnn_message_train": [_I] + [_P] * 11 + [_I] * 3 + [_P] * 4 + [_I, _P],
-    "mpnn_enc_edge_update_train": [_P] * 11 + [_I] * 3 + [_P] * 4 + [_F, ctypes.c_uint32, _P],
+    "mpnn_enc_edge_update_train": [_P] * 11 + [_I] * 3 + [_P] * 4 + [_F, ctypes.c_uint32, _P, _P],
     "mpnn_message_bwd": [_I] + [_P] * 8 + [_I] * 3 + [_P] * 4 + [_I, _P, _I, _P],
-    "mpnn_message_bwd_fused": [_I] + [_P] * 9 + [_I] * 3 + [_P] * 3 + [_I, _I] + [_P] * 4 + [_I, _P],
+    "mpnn_message_bwd_fused": [_I] + [_P] * 9 + [_I] * 3 + [_P] * 3 + [_I, _I] + [_P] * 5 + [_I, _P],
+    "mpnn_enc_edge_update_bwd_fused": [_P] * 8 + [_I] * 3 + [_P] * 12 + [_F, ctypes.c_uint32, _P, _I, _P],
     "mpnn_enc_edge_update_bwd": [_P] * 8 + [_I] * 3 + [_P] * 7 + [_F, ctypes.c_uint32, _P, _I, _P],
     "mpnn_edge_wgrad": [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P],
     "mpnn_gather_rows": [_P] * 6 + [_I, _I] + [_P] * 4,

@@ -22,6 +22,7 @@ extern "C" long long mpnn_workspace_bytes(const char* entry, int n_rows, int n_b
     return wg * part;
   }
   if (!strcmp(entry, "mpnn_message_bwd_fused")) return (64 + 256 * 2 * 16512LL) * (long long)sizeof(float);
+  if (!strcmp(entry, "mpnn_enc_edge_update_bwd_fused")) return (64 + 256 * (2 * 16512LL + 256)) * (long long)sizeof(float);
   if (!strcmp(entry, "mpnn_node_wgrad") || !strcmp(entry, "mpnn_node_wgrad_batch")) {
     // one partial per 128 x 128 output block and row chunk; chunks of >= 32 rows, at most 256 of them
     long long chunks = (n_rows + 31) / 32;

@@ -340,7 +340,8 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
                   const float* __restrict__ b12, const h8* __restrict__ W13, const float* __restrict__ b13,
                   const float* __restrict__ ln_w, const float* __restrict__ ln_b, int N, int L,
                   f32x4* __restrict__ hE_out, f32x4* __restrict__ sv1, f32x4* __restrict__ sv2,
-                  f32x4* __restrict__ svz, unsigned drop_thresh, unsigned drop_seed, float inv_keep) {
+                  f32x4* __restrict__ svz, unsigned drop_thresh, unsigned drop_seed, float inv_keep,
+                  unsigned* __restrict__ rstd_max) {
   __shared__ h8 lds[2 * WSPLIT + W3_LDS_FRAGS * 64];
   __shared__ __align__(16) float prm[4 * MPNN_H];
   lds_fill(lds, W11b, WSPLIT);
@@ -387,6 +388,7 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
     for (int c = 0; c < KT; ++c) h2[t][c] = row_tile(row[c], t);
 
   STAMP_DECL;
+  float rmx = 0.f;
   for (; node < Nend; node += stride) {
     const int nxt = (node + stride < Nend) ? node + stride : Nend - 1;
     STAMP(7);
@@ -528,6 +530,10 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
     // memory operations complete in issue order) - and the tiles are normalised and stored one by one
     float mean[KT], rstd[KT];
     tile_layernorm_stats<KT>(h1, mean, rstd);
+    if (SAVE) {  // the largest 1 / sigma of the launch: the backward kernel's operand-scale bound (mpnn_enc_edge_update_bwd_fused)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) rmx = fmaxf(rmx, rstd[c]);
+    }
     f32x4* xo = SAVE ? hE_out + soff : x;
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t) {
@@ -544,6 +550,11 @@ k_enc_edge_update(f32x4* __restrict__ hE, const float* __restrict__ Pb, int ldp,
       for (int c = 0; c < KT; ++c) __builtin_nontemporal_store(h1[t][c], &xo[(t * KT + c) * 64]);
     }
     STAMP(5);
+  }
+  if (SAVE && rstd_max) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) rmx = fmaxf(rmx, __shfl_xor(rmx, o));
+    if (lane == 0) atomicMax(rstd_max, (unsigned)__float_as_int(rmx));  // a maximum: order-independent
   }
   STAMP_FLUSH(8);
 }
@@ -1119,7 +1130,8 @@ extern "C" int MPNN_API(mpnn_enc_edge_update)(float* hE_frag, const float* PQ, i
   KT_DISPATCH(KT, hipLaunchKernelGGL((k_enc_edge_update<kKT, false>), grid, block, 0, (hipStream_t)stream,
                                      (f32x4*)hE_frag, PQ, ldpq, offP, PQ, ldpq, offQ, E_idx32, (const h8*)W11b_packed,
                                      (const h8*)W12_packed, b12, (const h8*)W13_packed, b13, ln_w, ln_b, N, L,
-                                     (f32x4*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr, 0u, 0u, 1.0f));
+                                     (f32x4*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr, (f32x4*)nullptr, 0u, 0u, 1.0f,
+                                     (unsigned*)nullptr));
   MPNN_LAUNCH_CHECK();
 }
 
@@ -1218,7 +1230,7 @@ extern "C" int mpnn_enc_edge_update_train(const float* hE_frag, const float* P, 
                                           const float* W13_packed, const float* b13, const float* ln_w,
                                           const float* ln_b, int B, int L, int K, float* hE_out, float* a1_frag,
                                           float* a2_frag, float* z_frag, float p_drop, uint32_t drop_seed,
-                                          void* stream) {
+                                          float* rstd_max, void* stream) {
   MPNN_CHECK_ARG(hE_frag && P && Q && E_idx32 && W11b_packed && W12_packed && b12 && W13_packed && b13 && ln_w &&
                      ln_b && hE_out && a1_frag && a2_frag && z_frag,
                  "mpnn_enc_edge_update_train: null pointer");
@@ -1232,7 +1244,7 @@ extern "C" int mpnn_enc_edge_update_train(const float* hE_frag, const float* P, 
                                      (f32x4*)hE_frag, P, 128, 0, Q, 128, 0, E_idx32, (const h8*)W11b_packed,
                                      (const h8*)W12_packed, b12, (const h8*)W13_packed, b13, ln_w, ln_b, N, L,
                                      (f32x4*)hE_out, (f32x4*)a1_frag, (f32x4*)a2_frag, (f32x4*)z_frag, thresh,
-                                     (unsigned)drop_seed, 1.0f / (1.0f - p_drop)));
+                                     (unsigned)drop_seed, 1.0f / (1.0f - p_drop), (unsigned*)rstd_max));
   MPNN_LAUNCH_CHECK();
 }
 #endif

@@ -570,7 +570,8 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
                     const f32x4* __restrict__ hE, const int* __restrict__ E_idx, const float* __restrict__ mask,
                     const float* __restrict__ edge_mask, const h8* __restrict__ W2T, const h8* __restrict__ W1bT, int N,
                     int L, int K, float* __restrict__ da1_nat, float* __restrict__ dP, f32x4* __restrict__ dE,
-                    int accumulate, int w_valid, const unsigned* __restrict__ scales, float* __restrict__ part) {
+                    int accumulate, int w_valid, const unsigned* __restrict__ scales, float* __restrict__ part,
+                    unsigned* __restrict__ amax_out) {
   __shared__ h8 Bf[2][NKK][KT][2][64];
   __shared__ _Float16 sA[2][2][MPNN_H][FB_LDK];
   __shared__ _Float16 sB[2][2][MPNN_H][FB_LDK];
@@ -598,6 +599,7 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
 #pragma unroll
   for (int j = 0; j < MPNN_NT; ++j) accW2[j] = accW1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 bacc = f32x4{0.f, 0.f, 0.f, 0.f};
+  float vmax = 0.f;
   // where this lane's share of a (feature tile, column tile) goes in the planes / in a B fragment
   const int frow = 16 * wave + 4 * g + (col & 3);
   const int bf_kk = wave >> 1, bf_half = (wave & 1) * 4;  // halves [bf_half, bf_half + 4) of k-step bf_kk
@@ -798,11 +800,17 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
       for (int c = 0; c < KT; ++c) {
         f32x4 v = gemm_tile(1, c, w1h, w1l) * un2;
         if (accumulate) v += pe[c];
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         __builtin_nontemporal_store(v, &dst[tile_off + (unsigned)c * 64u]);
         FENCE();
       }
     }
     contract(1, accW1);
+  }
+  if (amax_out) {  // max |dE| as written: the operand-scale bound of the kernel that takes dE as its dy
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if (lane == 0) atomicMax(amax_out, (unsigned)__float_as_int(vmax));  // a maximum: order-independent
   }
   // this workgroup's partial sums: [dW2 | db2] and [dW1b | -]
   float* P = part + (size_t)blockIdx.x * 2 * WG_PART;
@@ -820,6 +828,353 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
       P[MPNN_H * MPNN_H + 16 * wave + 4 * g + r] = v;
       P[WG_PART + MPNN_H * MPNN_H + 16 * wave + 4 * g + r] = 0.f;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Encoder edge-update backward with its THREE weight-gradient contractions fused in (K <= 48): what
+// mpnn_enc_edge_update_bwd + 3 x mpnn_edge_wgrad do, in the workgroup-per-residue form of k_message_bwd_fused - dz and
+// da2 never exist in memory, a2 / a1 / hE / the da1 rows are read once (7 instead of 16 edge tensors of traffic).
+//   stage 0: dz = LayerNorm'(dy; z), dzd = dropout(dz)      dW13 += dzd (x) gelu(a2)   dg2 = W13^T dzd
+//   stage 1: da2 = dg2 gelu'(a2)                            dW12 += da2 (x) gelu(a1)   dg1 = W12^T da2
+//   stage 2: da1 = dg1 gelu'(a1) (rows for dQ', dP')        dW11b += da1 (x) e         dE = dz + W11b^T da1
+// A wave owns 16 of the 128 features, so the LayerNorm's per-edge sums over the features cross the waves: ONE exchange
+// of four partial sums per edge (sum z, sum z^2, sum dy g, sum dy g z) through LDS gives mean, rstd, mean(dxhat) and
+// mean(dxhat xhat) together - four barriers per residue (exchange + three stages).  Stage buffers: stage 2 re-uses stage
+// 0's (consumed before barrier B).  All three transposed weights stream from L2 (16 rows per wave and GEMM); the three
+// 16 x 128 accumulator blocks, the bias and LayerNorm-parameter sums take 112 registers.
+// Launch-wide power-of-two operand scales from BOUNDS (k_fused_scales3): |dz| <= 13.3 rstd_max max|g| max|dy| (the forward
+// kernel records rstd_max, the producers of dy record max|dy|), then 1.13 ||W^T||_1-row per GEMM.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(128)
+k_fused_scales3(const unsigned* __restrict__ dy_amax, const unsigned* __restrict__ rstd_max,
+                const float* __restrict__ ln_w, const h8* __restrict__ W13T, const h8* __restrict__ W12T, float inv_keep,
+                unsigned* __restrict__ scales) {
+  __shared__ float red[3][2];
+  const int to = threadIdx.x >> 4, col = threadIdx.x & 15;
+  float s13 = 0.f, s12 = 0.f;
+  for (int kk = 0; kk < NKK; ++kk)
+    for (int g = 0; g < 4; ++g) {
+      const size_t i = ((size_t)(to * NKK + kk) * 2) * 64 + 16 * g + col;
+      const h8 h3 = W13T[i], l3 = W13T[i + 64], h2 = W12T[i], l2 = W12T[i + 64];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        s13 += fabsf((float)h3[q] + (float)l3[q]);
+        s12 += fabsf((float)h2[q] + (float)l2[q]);
+      }
+    }
+  float gm = fabsf(ln_w[threadIdx.x]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    s13 = fmaxf(s13, __shfl_xor(s13, o));
+    s12 = fmaxf(s12, __shfl_xor(s12, o));
+    gm = fmaxf(gm, __shfl_xor(gm, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s13;
+    red[1][threadIdx.x >> 6] = s12;
+    red[2][threadIdx.x >> 6] = gm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float S13 = fmaxf(red[0][0], red[0][1]), S12 = fmaxf(red[1][0], red[1][1]), G = fmaxf(red[2][0], red[2][1]);
+    const float m0 = 13.3f * __int_as_float((int)rstd_max[0]) * G * __int_as_float((int)dy_amax[0]) * inv_keep;
+    const float m1 = 1.1293f * S13 * m0;
+    const float m2 = 1.1293f * S12 * m1;
+    scales[0] = (unsigned)__float_as_int(m0);
+    scales[1] = (unsigned)__float_as_int(m1);
+    scales[2] = (unsigned)__float_as_int(m2);
+  }
+}
+
+constexpr int EU_PART = 2 * WG_PART + 2 * MPNN_H;  // floats of one workgroup's partial sums
+
+template <int KT>
+__global__ void __launch_bounds__(FB_WAVES * 64)
+k_edge_update_bwd_fused(const f32x4* __restrict__ dy, const f32x4* __restrict__ z, const f32x4* __restrict__ a2,
+                        const f32x4* __restrict__ a1, const float* __restrict__ ln_w,
+                        const h8* __restrict__ W13T, const h8* __restrict__ W12T, const h8* __restrict__ W11bT, int N,
+                        float* __restrict__ da1_nat, float* __restrict__ dP, f32x4* __restrict__ dE,
+                        const unsigned* __restrict__ scales, float* __restrict__ part, unsigned* __restrict__ amax_out,
+                        unsigned* __restrict__ amax_rows,
+                        unsigned drop_thresh, unsigned drop_seed, float inv_keep) {
+  __shared__ h8 Bf[2][NKK][KT][2][64];
+  __shared__ _Float16 sA[2][MPNN_H][FB_LDK];  // a wave reads only the rows it wrote: one buffer, publish -> contract in order
+  __shared__ _Float16 sB[2][2][MPNN_H][FB_LDK];
+  __shared__ f32x4 red[FB_WAVES][KT][16];
+  __shared__ f32x4 park[FB_WAVES][KT][64];    // dz of the residue (the residual term of dE), out of the registers
+  __shared__ float sacc[4][MPNN_H];           // db13 | db12 | dgamma | dbeta: one writer lane per word, in residue order
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  constexpr int Kp = KT * 16;
+  float sc[3], un[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    sc[i] = pow2_scale_from_bits(scales[i]);
+    un[i] = pow2_inverse(sc[i]);
+  }
+  f32x4 acc13[MPNN_NT], acc12[MPNN_NT];
+#pragma unroll
+  for (int j = 0; j < MPNN_NT; ++j) acc13[j] = acc12[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (threadIdx.x < MPNN_H) sacc[0][threadIdx.x] = sacc[1][threadIdx.x] = sacc[2][threadIdx.x] = sacc[3][threadIdx.x] = 0.f;
+  // (first touched after the first barrier of the loop)
+  auto sacc_add = [&](int q, f32x4 v) {  // per-feature sums over the residue's edges -> the workgroup's running sums
+    v = column_sum4(v);
+    if (col == 0) {
+      f32x4* p = reinterpret_cast<f32x4*>(&sacc[q][16 * wave + 4 * g]);
+      *p += v;
+    }
+  };
+  float vmax = 0.f, rmax = 0.f;
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(ln_w + 16 * wave + 4 * g);
+  const int frow = 16 * wave + 4 * g + (col & 3);
+  const int bf_kk = wave >> 1, bf_half = (wave & 1) * 4;
+  const int G = gridDim.x;
+
+  auto contract = [&](int st, f32x4 (&acc)[MPNN_NT]) {
+    h4 bh[2][2], bl[2][2];
+    auto rd = [&](int buf, int c, int j0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bh[buf][u] = *reinterpret_cast<const h4*>(&sB[st][0][16 * (j0 + u) + col][16 * c + 4 * g]);
+        bl[buf][u] = *reinterpret_cast<const h4*>(&sB[st][1][16 * (j0 + u) + col][16 * c + 4 * g]);
+      }
+    };
+    rd(0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      const h4 ah = *reinterpret_cast<const h4*>(&sA[0][16 * wave + col][16 * c + 4 * g]);
+      const h4 al = *reinterpret_cast<const h4*>(&sA[1][16 * wave + col][16 * c + 4 * g]);
+#pragma unroll
+      for (int jp = 0; jp < MPNN_NT / 2; ++jp) {
+        const int cur = (c * (MPNN_NT / 2) + jp) & 1;
+        if (jp + 1 < MPNN_NT / 2) rd(cur ^ 1, c, 2 * (jp + 1));
+        else if (c + 1 < KT) rd(cur ^ 1, c + 1, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int j = 2 * jp + u;
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh[cur][u], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl[cur][u], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh[cur][u], acc[j], 0, 0, 0);
+        }
+        FENCE();
+      }
+    }
+  };
+  auto publish_grad = [&](int st, int c, const f32x4 x) {
+    h4 hh, ll;
+    split4(x, hh, ll);
+    _Float16* bh = reinterpret_cast<_Float16*>(&Bf[st][bf_kk][c][0][lane]) + bf_half;
+    _Float16* bl = reinterpret_cast<_Float16*>(&Bf[st][bf_kk][c][1][lane]) + bf_half;
+    *reinterpret_cast<h4*>(bh) = hh;
+    *reinterpret_cast<h4*>(bl) = ll;
+    split4(quad_transpose(x), hh, ll);
+    const int ecol = 16 * c + 4 * (col >> 2);
+    *reinterpret_cast<h4*>(&sA[0][frow][ecol]) = hh;
+    *reinterpret_cast<h4*>(&sA[1][frow][ecol]) = ll;
+  };
+  auto publish_bf = [&](int st, int c, const f32x4 x) {  // B fragments only (no contraction follows in this kernel)
+    h4 hh, ll;
+    split4(x, hh, ll);
+    _Float16* bh = reinterpret_cast<_Float16*>(&Bf[st][bf_kk][c][0][lane]) + bf_half;
+    _Float16* bl = reinterpret_cast<_Float16*>(&Bf[st][bf_kk][c][1][lane]) + bf_half;
+    *reinterpret_cast<h4*>(bh) = hh;
+    *reinterpret_cast<h4*>(bl) = ll;
+  };
+  auto publish_act = [&](int st, int c, const f32x4 v) {
+    h4 hh, ll;
+    split4(quad_transpose(v), hh, ll);
+    const int ecol = 16 * c + 4 * (col >> 2);
+    *reinterpret_cast<h4*>(&sB[st][0][frow][ecol]) = hh;
+    *reinterpret_cast<h4*>(&sB[st][1][frow][ecol]) = ll;
+  };
+  auto gemm_tile = [&](int st, int c, const h8 (&wh)[NKK], const h8 (&wl)[NKK]) {
+    f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
+    BFrag b[2];
+    b[0].hi = Bf[st][0][c][0][lane];
+    b[0].lo = Bf[st][0][c][1][lane];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      if (kk + 1 < NKK) {
+        b[(kk + 1) & 1].hi = Bf[st][kk + 1][c][0][lane];
+        b[(kk + 1) & 1].lo = Bf[st][kk + 1][c][1][lane];
+      }
+      y = mfma_split(wh[kk], wl[kk], b[kk & 1], y);
+      FENCE();
+    }
+    return y;
+  };
+  // this wave's 16 rows of a transposed weight, from L2 (requested one phase ahead of their GEMM)
+  auto load_w = [&](const h8* WT, h8 (&wh)[NKK], h8 (&wl)[NKK]) {
+    const h8* base = WT + (size_t)wave * NKK * 2 * 64 + lane;
+    auto Wp = GLOBAL(base);
+    LAUNDER(Wp);
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      wh[kk] = Wp[(kk * 2 + 0) * 64];
+      wl[kk] = Wp[(kk * 2 + 1) * 64];
+    }
+  };
+  const unsigned tile_off = (unsigned)(wave * KT) * 64u + (unsigned)lane;
+  auto tile_of = [&](const f32x4* base, int node) {
+    return base + (size_t)__builtin_amdgcn_readfirstlane(node) * (MPNN_NT * KT * 64);
+  };
+  auto load_tile = [&](f32x4 (&dst)[KT], const f32x4* base, int node) {
+    const f32x4* p = tile_of(base, node);
+#pragma unroll
+    for (int c = 0; c < KT; ++c) dst[c] = __builtin_nontemporal_load(&p[tile_off + (unsigned)c * 64u]);
+  };
+  const unsigned row_off = (unsigned)col * MPNN_H + (unsigned)(16 * wave + 4 * g);
+
+  f32x4 zt[KT], dt[KT], t2[KT], t1[KT];
+  int node = blockIdx.x;
+  if (node < N) {
+    load_tile(zt, z, node);
+    load_tile(dt, dy, node);
+    load_tile(t2, a2, node);
+  }
+  for (; node < N; node += G) {
+    const int nxt = node + G;
+    const bool more = nxt < N;
+    // ---- LayerNorm exchange: four partial sums per edge over this wave's 16 features
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      const f32x4 dg = dt[c] * gm;
+      f32x4 sm;
+      sm.x = (zt[c].x + zt[c].y) + (zt[c].z + zt[c].w);
+      sm.y = (zt[c].x * zt[c].x + zt[c].y * zt[c].y) + (zt[c].z * zt[c].z + zt[c].w * zt[c].w);
+      sm.z = (dg.x + dg.y) + (dg.z + dg.w);
+      sm.w = (dg.x * zt[c].x + dg.y * zt[c].y) + (dg.z * zt[c].z + dg.w * zt[c].w);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sm[r] = quarter_sum(sm[r]);
+      if (g == 0) red[wave][c][col] = sm;
+    }
+    load_tile(t1, a1, node);
+    FENCE();
+    __syncthreads();  // L
+    // ---- stage 0: dz, its dropout, fragments and planes; planes of gelu(a2); t2 <- gelu'(a2)
+    f32x4 bacc13 = f32x4{0.f, 0.f, 0.f, 0.f}, lg = bacc13, lb = bacc13;
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      // lane quarter g adds the partials of waves 2g and 2g + 1, the quarters meet by two shuffles
+      f32x4 tot = red[2 * g][c][col] + red[2 * g + 1][c][col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tot[r] = quarter_sum(tot[r]);
+      const float mean = tot.x * (1.0f / MPNN_H);
+      const float rstd = rsqrtf(fmaxf(tot.y * (1.0f / MPNN_H) - mean * mean, 0.f) + MPNN_LN_EPS);
+      const float m1 = tot.z * (1.0f / MPNN_H);
+      const float m2 = rstd * (tot.w * (1.0f / MPNN_H) - mean * m1);
+      const f32x4 xh = (zt[c] - mean) * rstd;
+      lg += dt[c] * xh;
+      lb += dt[c];
+      const f32x4 dz = (dt[c] * gm - m1 - xh * m2) * rstd;
+      park[wave][c][lane] = dz;
+      f32x4 dzd = dz;
+      if (drop_thresh)
+        dzd = dropout4(dz, ((unsigned)__builtin_amdgcn_readfirstlane(node) * (unsigned)(MPNN_NT * KT * 64) + tile_off +
+                            (unsigned)c * 64u) * 4u,
+                       drop_seed, drop_thresh, inv_keep);
+      bacc13 += dzd;
+      publish_grad(0, c, dzd * sc[0]);
+      publish_act(0, c, gelu4(t2[c]));
+      t2[c] = gelu_grad4(t2[c]);
+      FENCE();
+    }
+    sacc_add(0, bacc13);
+    sacc_add(2, lg);
+    sacc_add(3, lb);
+    FENCE();
+    h8 wh[NKK], wl[NKK];
+    load_w(W13T, wh, wl);
+    FENCE();
+    __syncthreads();  // A
+    // ---- stage 1: dW13 += dzd (x) gelu(a2) first (the A planes are single-buffered), then da2 = (W13^T dzd) gelu'(a2),
+    //      its fragments and planes, the planes of gelu(a1); t1 <- gelu'(a1)
+    contract(0, acc13);
+    f32x4 bacc12 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      f32x4 y = gemm_tile(0, c, wh, wl);
+      y *= t2[c] * un[0];
+      bacc12 += y;
+      publish_grad(1, c, y * sc[1]);
+      publish_act(1, c, gelu4(t1[c]));
+      t1[c] = gelu_grad4(t1[c]);
+      FENCE();
+    }
+    sacc_add(1, bacc12);
+    FENCE();
+    load_w(W12T, wh, wl);
+    FENCE();
+    __syncthreads();  // B
+    // ---- stage 2: dW12 += da2 (x) gelu(a1); da1 = (W12^T da2) gelu'(a1): rows, dP, fragments (stage 0's buffer)
+    contract(1, acc12);
+    f32x4 ps = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      f32x4 y = gemm_tile(1, c, wh, wl);
+      y *= t1[c] * un[1];
+      ps += y;
+      rmax = fmaxf(fmaxf(rmax, fmaxf(fabsf(y.x), fabsf(y.y))), fmaxf(fabsf(y.z), fabsf(y.w)));
+      {
+        float* rb = da1_nat + (size_t)__builtin_amdgcn_readfirstlane(node) * (Kp * MPNN_H);
+        __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(&rb[row_off + (unsigned)(16 * c) * MPNN_H]));
+      }
+      publish_bf(0, c, y * sc[2]);
+      FENCE();
+    }
+    ps = column_sum4(ps);
+    if (col == 0) {
+      float* pb = dP + (size_t)__builtin_amdgcn_readfirstlane(node) * MPNN_H;
+      *reinterpret_cast<f32x4*>(&pb[(unsigned)(16 * wave + 4 * g)]) = ps;
+    }
+    FENCE();
+    load_w(W11bT, wh, wl);
+    FENCE();
+    __syncthreads();  // C
+    // ---- stage 3: dE = dz + W11b^T da1; dW11b += da1 (x) e
+    {
+      f32x4* dst = const_cast<f32x4*>(tile_of(dE, node));
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        const f32x4 v = gemm_tile(0, c, wh, wl) * un[2] + park[wave][c][lane];
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        __builtin_nontemporal_store(v, &dst[tile_off + (unsigned)c * 64u]);
+        FENCE();
+      }
+    }
+    if (more) {
+      load_tile(zt, z, nxt);
+      load_tile(dt, dy, nxt);
+      load_tile(t2, a2, nxt);
+    }
+    FENCE();
+  }
+  // this workgroup's partial sums: [dW13 | db13] [dW12 | db12] [dgamma | dbeta]
+  float* P = part + (size_t)blockIdx.x * EU_PART;
+#pragma unroll
+  for (int j = 0; j < MPNN_NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = (16 * wave + 4 * g + r) * MPNN_H + 16 * j + col;
+      P[o] = acc13[j][r] * un[0];
+      P[WG_PART + o] = acc12[j][r] * un[1];
+    }
+  __syncthreads();
+  if (threadIdx.x < MPNN_H) {
+    P[MPNN_H * MPNN_H + threadIdx.x] = sacc[0][threadIdx.x];
+    P[WG_PART + MPNN_H * MPNN_H + threadIdx.x] = sacc[1][threadIdx.x];
+    P[2 * WG_PART + threadIdx.x] = sacc[2][threadIdx.x];
+    P[2 * WG_PART + MPNN_H + threadIdx.x] = sacc[3][threadIdx.x];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    rmax = fmaxf(rmax, __shfl_xor(rmax, o));
+  }
+  if (lane == 0) {  // maxima: order-independent
+    if (amax_out) atomicMax(amax_out, (unsigned)__float_as_int(vmax));
+    atomicMax(amax_rows, (unsigned)__float_as_int(rmax));
   }
 }
 
@@ -939,8 +1294,8 @@ extern "C" int mpnn_message_bwd_fused(int dec, const float* dgsum, const float* 
                                      const float* hE_frag, const int32_t* E_idx32, const float* mask,
                                      const float* edge_mask, const float* W2T_packed, const float* W1bT_packed, int B,
                                      int L, int K, float* da1_rows, float* dP, float* dE_frag, int accumulate,
-                                     int w_valid, float* dW2, float* db2, float* dW1b, float* workspace,
-                                     int workspace_floats, void* stream) {
+                                     int w_valid, float* dW2, float* db2, float* dW1b, float* dE_absmax,
+                                     float* workspace, int workspace_floats, void* stream) {
   MPNN_CHECK_ARG(dgsum && a1_frag && a2_frag && hE_frag && E_idx32 && mask && W2T_packed && W1bT_packed && da1_rows &&
                      dP && dE_frag && dW2 && db2 && dW1b && workspace,
                  "mpnn_message_bwd_fused: null pointer");
@@ -957,7 +1312,8 @@ extern "C" int mpnn_message_bwd_fused(int dec, const float* dgsum, const float* 
 #define MPNN_FB_LAUNCH(kt, DECV)                                                                                     \
   hipLaunchKernelGGL((k_message_bwd_fused<kt, DECV>), grid, block, 0, st, dgsum, (const f32x4*)a1_frag,               \
                      (const f32x4*)a2_frag, (const f32x4*)hE_frag, E_idx32, mask, edge_mask, (const h8*)W2T_packed,  \
-                     (const h8*)W1bT_packed, N, L, K, da1_rows, dP, (f32x4*)dE_frag, accumulate, w_valid, scales, workspace)
+                     (const h8*)W1bT_packed, N, L, K, da1_rows, dP, (f32x4*)dE_frag, accumulate, w_valid, scales, workspace, \
+                     (unsigned*)dE_absmax)
   if (hipMemsetAsync(scales, 0, 2 * sizeof(unsigned), st) != hipSuccess) {
     mpnn_set_error("mpnn_message_bwd_fused: hipMemsetAsync failed");
     return 1;
@@ -1001,6 +1357,46 @@ extern "C" int mpnn_enc_edge_update_bwd(const float* dy_frag, const float* z_fra
                                  (f32x4*)dE_frag, workspace, (unsigned*)amax3, thresh, (unsigned)drop_seed,
                                  1.0f / (1.0f - p_drop)));
   launch_partials_reduce(workspace, (int)grid.x, 2 * MPNN_H, 2 * MPNN_H, dln, 1, (hipStream_t)stream);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_enc_edge_update_bwd_fused(const float* dy_frag, const float* z_frag, const float* a2_frag,
+                                              const float* a1_frag, const float* ln_w, const float* W13T_packed,
+                                              const float* W12T_packed, const float* W11bT_packed, int B, int L, int K,
+                                              float* da1_rows, float* da1_absmax, float* dP, float* dE_frag, float* dln,
+                                              float* dW13, float* db13, float* dW12, float* db12, const float* dy_absmax,
+                                              const float* rstd_max, float* dE_absmax, float p_drop, uint32_t drop_seed,
+                                              float* workspace, int workspace_floats, void* stream) {
+  MPNN_CHECK_ARG(dy_frag && z_frag && a2_frag && a1_frag && ln_w && W13T_packed && W12T_packed && W11bT_packed &&
+                     da1_rows && da1_absmax && dP && dE_frag && dln && dW13 && db13 && dW12 && db12 && dy_absmax &&
+                     rstd_max && workspace,
+                 "mpnn_enc_edge_update_bwd_fused: null pointer");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 48,
+                 "mpnn_enc_edge_update_bwd_fused: bad sizes (K <= 48; above: mpnn_enc_edge_update_bwd)");
+  MPNN_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mpnn_enc_edge_update_bwd_fused: dropout probability must be in [0, 1)");
+  const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
+  const int N = B * L, KT = (K + 15) / 16;
+  int nwg = edge_grid(N, 1);
+  if (nwg > (workspace_floats - 64) / EU_PART) nwg = (workspace_floats - 64) / EU_PART;
+  MPNN_CHECK_ARG(nwg >= 1, "mpnn_enc_edge_update_bwd_fused: workspace holds no partial (64 + 33280 floats per workgroup, one per CU)");
+  unsigned* scales = reinterpret_cast<unsigned*>(workspace);
+  workspace += 64;
+  hipStream_t st = (hipStream_t)stream;
+  const float inv_keep = 1.0f / (1.0f - p_drop);
+  hipLaunchKernelGGL(k_fused_scales3, dim3(1), dim3(128), 0, st, (const unsigned*)dy_absmax, (const unsigned*)rstd_max,
+                     ln_w, (const h8*)W13T_packed, (const h8*)W12T_packed, inv_keep, scales);
+  dim3 grid(nwg), block(FB_WAVES * 64);
+#define MPNN_EU_LAUNCH(kt)                                                                                             \
+  hipLaunchKernelGGL((k_edge_update_bwd_fused<kt>), grid, block, 0, st, (const f32x4*)dy_frag, (const f32x4*)z_frag,    \
+                     (const f32x4*)a2_frag, (const f32x4*)a1_frag, ln_w, (const h8*)W13T_packed,                         \
+                     (const h8*)W12T_packed, (const h8*)W11bT_packed, N, da1_rows, dP, (f32x4*)dE_frag, scales,        \
+                     workspace, (unsigned*)dE_absmax, (unsigned*)da1_absmax, thresh, (unsigned)drop_seed, inv_keep)
+  if (KT == 1) MPNN_EU_LAUNCH(1); else if (KT == 2) MPNN_EU_LAUNCH(2); else MPNN_EU_LAUNCH(3);
+#undef MPNN_EU_LAUNCH
+  const dim3 rg((WG_PART + 15) / 16), rb(256);
+  hipLaunchKernelGGL(k_wgrad_reduce, rg, rb, 0, st, workspace, nwg, (size_t)EU_PART, dW13, db13);
+  hipLaunchKernelGGL(k_wgrad_reduce, rg, rb, 0, st, workspace + WG_PART, nwg, (size_t)EU_PART, dW12, db12);
+  launch_partials_reduce(workspace + 2 * WG_PART, nwg, EU_PART, 2 * MPNN_H, dln, 1, st);
   MPNN_LAUNCH_CHECK();
 }
 

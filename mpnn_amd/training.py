@@ -133,6 +133,8 @@ def _pack_blocks(blocks):
 
 # mpnn_message_bwd_fused (K <= 48) instead of mpnn_message_bwd + 2 x mpnn_edge_wgrad
 FUSED_MSG_BWD = os.environ.get("MPNN_FUSED_MSG_BWD", "1") != "0"
+# mpnn_enc_edge_update_bwd_fused (K <= 48) instead of mpnn_enc_edge_update_bwd + 2 of its 3 mpnn_edge_wgrad passes
+FUSED_UPD_BWD = os.environ.get("MPNN_FUSED_UPD_BWD", "1") != "0"
 
 
 def _wgrad(A, a_rows, amax, Bfrag, b_gelu, g, want_bias):
@@ -162,6 +164,7 @@ class _ZeroArena:
 
     def __init__(self):
         self.buf = None
+        self.amax = None   # one float on the device: max |buf| as its writers left it (the fused kernels' dE_absmax)
         self.used = 0
 
     def reset(self, dev, n_floats=4 << 20):
@@ -195,6 +198,7 @@ def _workspace(dev, n_rows=0):
     lib = _lib.load()
     need = max(lib.mpnn_workspace_bytes(b"mpnn_edge_wgrad", 1 << 30, 1),
                lib.mpnn_workspace_bytes(b"mpnn_message_bwd_fused", 0, 0),
+               lib.mpnn_workspace_bytes(b"mpnn_enc_edge_update_bwd_fused", 0, 0),
                lib.mpnn_workspace_bytes(b"mpnn_enc_edge_update_bwd", 0, 0),
                lib.mpnn_workspace_bytes(b"mpnn_logits_log_softmax_bwd", int(n_rows), 0),
                lib.mpnn_workspace_bytes(b"mpnn_node_update_bwd", int(n_rows), 0)) // 4
@@ -293,6 +297,7 @@ class GradSlot:
 
     def __init__(self):
         self.buf = None
+        self.amax = None   # one float on the device: max |buf| as its writers left it (the fused kernels' dE_absmax)
 
 
 # ---------------------------------------------------------------------------
@@ -340,19 +345,23 @@ class MessageFn(torch.autograd.Function):
         first = slot.buf is None
         if first:
             slot.buf = torch.empty_like(a1)
+            slot.amax = None
         dE = slot.buf
         w2t, w1t = _pack_blocks([(W2, True), (W1b, True)])
         if FUSED_MSG_BWD and g.K <= 48:
             # one kernel: chain + both weight-gradient contractions (da2 never exists in memory)
             dW2, db2, dW1b = _zeros(dev, H, H), _zeros(dev, H), _zeros(dev, H, H)
             ws = _workspace(dev)
+            if first:
+                slot.amax = _zeros(dev, 1)
             call("mpnn_message_bwd_fused", int(dec), ptr(dgsum), ptr(a1), ptr(a2), ptr(hE), ptr(g.E_idx32), ptr(g.mask),
                  ptr(g.edge_mask), ptr(w2t), ptr(w1t), g.B, g.L, g.K, ptr(rows), ptr(dP), ptr(dE), 0 if first else 1,
-                 ctx.w_valid, ptr(dW2), ptr(db2), ptr(dW1b), ptr(ws), ws.numel(), stream_ptr())
+                 ctx.w_valid, ptr(dW2), ptr(db2), ptr(dW1b), ptr(slot.amax), ptr(ws), ws.numel(), stream_ptr())
             dRowA, dRowB = _gather(rows, g, g.sel if dec else None)
             return None, None, None, dE if first else None, dP, dRowA, dRowB, dW1b, dW2, db2
         da2 = torch.empty_like(a1)
         amax = _zeros(dev, 2)
+        slot.amax = None  # this writer records no max |dE|
         call("mpnn_message_bwd", int(dec), ptr(dgsum), ptr(a1), ptr(a2), ptr(g.E_idx32), ptr(g.mask), ptr(g.edge_mask),
              ptr(w2t), ptr(w1t), g.B, g.L, g.K, ptr(da2), ptr(rows),
              ptr(dP), ptr(dE), 0 if first else 1, ptr(amax), ctx.w_valid, stream_ptr())
@@ -374,10 +383,12 @@ class EdgeUpdateFn(torch.autograd.Function):
         a1, a2, z = torch.empty_like(hE), torch.empty_like(hE), torch.empty_like(hE)
         vec = [t.detach().contiguous() for t in (b12, b13, lnw, lnb)]
         w1p, w2p, w3p = _pack_blocks([(W11b, False), (W12, False), (W13, False)])
+        rstd_max = _zeros(dev, 1)
         call("mpnn_enc_edge_update_train", ptr(hE), ptr(P), ptr(Q), ptr(g.E_idx32), ptr(w1p),
              ptr(w2p), ptr(vec[0]), ptr(w3p), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), g.B, g.L,
-             g.K, ptr(out), ptr(a1), ptr(a2), ptr(z), float(p_drop), int(seed), stream_ptr())
+             g.K, ptr(out), ptr(a1), ptr(a2), ptr(z), float(p_drop), int(seed), ptr(rstd_max), stream_ptr())
         ctx.g, ctx.slot, ctx.out_slot, ctx.drop = g, slot, out_slot, (float(p_drop), int(seed))
+        ctx.rstd_max = rstd_max
         ctx.save_for_backward(hE, a1, a2, z, W11b, W12, W13, lnw)
         return out
 
@@ -388,16 +399,37 @@ class EdgeUpdateFn(torch.autograd.Function):
         hE, a1, a2, z, W11b, W12, W13, lnw = ctx.saved_tensors
         dev = hE.device
         dy = dy.contiguous()
-        ctx.out_slot.buf = None  # every consumer of this kernel's output has run: its gradient buffer is spent
+        out_slot = ctx.out_slot
+        # max |dy|: what the fused kernels that wrote it recorded, when dy IS their buffer; else two small ATen launches
+        dy_amax = out_slot.amax if (out_slot.buf is not None and out_slot.amax is not None
+                                    and out_slot.buf.data_ptr() == dy.data_ptr()) else None
+        out_slot.buf, out_slot.amax = None, None  # every consumer of this kernel's output has run: its buffer is spent
         assert ctx.slot.buf is None, "the edge update is the first consumer of its input to run backward"
-        dz, da2, dE = torch.empty_like(hE), torch.empty_like(hE), torch.empty_like(hE)
+        dE = torch.empty_like(hE)
         ctx.slot.buf = dE
         rows = torch.empty(g.N * g.Kp, H, device=dev, dtype=torch.float32)
         dP = torch.empty(g.N, H, device=dev, dtype=torch.float32)
         dln = _zeros(dev, 2 * H)
-        amax = _zeros(dev, 3)
         w3t, w2t, w1t = _pack_blocks([(W13, True), (W12, True), (W11b, True)])
         ws = _workspace(dev)
+        if FUSED_UPD_BWD and g.K <= 48:
+            # one kernel: LayerNorm', the chain and the W13 / W12 weight-gradient contractions (dz, da2 never exist in
+            # memory); the W11b contraction reads the rows it wrote
+            if dy_amax is None:
+                dy_amax = dy.abs().max().reshape(1)
+            dW13, db13, dW12, db12 = _zeros(dev, H, H), _zeros(dev, H), _zeros(dev, H, H), _zeros(dev, H)
+            amax = _zeros(dev, 2)
+            ctx.slot.amax = amax[1:2]
+            call("mpnn_enc_edge_update_bwd_fused", ptr(dy), ptr(z), ptr(a2), ptr(a1), ptr(lnw.detach().contiguous()),
+                 ptr(w3t), ptr(w2t), ptr(w1t), g.B, g.L, g.K, ptr(rows), ptr(amax[0:1]), ptr(dP), ptr(dE), ptr(dln),
+                 ptr(dW13), ptr(db13), ptr(dW12), ptr(db12), ptr(dy_amax), ptr(ctx.rstd_max), ptr(amax[1:2]),
+                 ctx.drop[0], ctx.drop[1], ptr(ws), ws.numel(), stream_ptr())
+            dQ, _ = _gather(rows, g, None)
+            dW11b, _ = _wgrad(rows, True, amax[0:1], hE, False, g, False)
+            return None, None, None, None, None, dE, dP, dQ, dW11b, dW12, db12, dW13, db13, dln[:H], dln[H:]
+        dz, da2 = torch.empty_like(hE), torch.empty_like(hE)
+        amax = _zeros(dev, 3)
+        ctx.slot.amax = None
         call("mpnn_enc_edge_update_bwd", ptr(dy), ptr(z), ptr(a2), ptr(a1), ptr(lnw.detach().contiguous()),
              ptr(w3t), ptr(w2t), ptr(w1t),
              g.B, g.L, g.K, ptr(dz), ptr(da2), ptr(rows), ptr(dP), ptr(dE), ptr(dln), ptr(amax), ctx.drop[0], ctx.drop[1],
