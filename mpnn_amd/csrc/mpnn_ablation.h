@@ -30,6 +30,9 @@
 //     MPNN_ABL_NODMA          matrices not staged by LDS-DMA
 //   weight gradient (mpnn_edge_bwd.hip)
 //     MPNN_ABL_WGRAD_STREAM   operand streams alone (no LDS transposes, no MFMAs)
+//   fused backward kernels (mpnn_edge_bwd.hip: k_message_bwd_fused, k_edge_update_bwd_fused)
+//     MPNN_ABL_FUSED_SAMELOAD every operand tile read hits the workgroup's first residue (L2): no HBM read latency
+//     MPNN_ABL_FUSED_NOBARRIER no workgroup barriers (races: what the lock-step costs)
 //
 // (The measured-and-rejected kernel VARIANTS - tile-wise kernels at K <= 48, burst prefetches, LDS read-ahead rings,
 // staggered half-workgroups, alternative load placements, the whole-level sampler kernel, the fp32-MFMA node weight
@@ -42,7 +45,8 @@
     defined(MPNN_ABL_NORES) || defined(MPNN_ABL_NOLN) || defined(MPNN_ABL_NOSTORE) ||                           \
     defined(MPNN_ABL_LEVEL_NOFILL) || defined(MPNN_ABL_LEVEL_NOMSG) || defined(MPNN_ABL_LEVEL_NONODE) ||        \
     defined(MPNN_ABL_SAMPLE_NOGEMM) || defined(MPNN_ABL_SAMPLE_NOLOOP) || defined(MPNN_ABL_SAMPLE_NOTAIL) ||    \
-    defined(MPNN_ABL_NODMA) || defined(MPNN_ABL_WGRAD_STREAM)
+    defined(MPNN_ABL_NODMA) || defined(MPNN_ABL_WGRAD_STREAM) || defined(MPNN_ABL_FUSED_SAMELOAD) ||             \
+    defined(MPNN_ABL_FUSED_NOBARRIER)
 #define MPNN_ABLATION_BUILD 1
 #else
 #define MPNN_ABLATION_BUILD 0

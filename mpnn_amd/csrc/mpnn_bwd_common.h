@@ -22,9 +22,42 @@ __device__ __forceinline__ float gelu_grad(float x) {
 }
 
 __device__ __forceinline__ f32x4 gelu_grad4(f32x4 v) {
+#ifdef MPNN_ABL_NOGELU  // timing-only ablation build: never shipped
+  return v;
+#endif
   f32x4 o;
   o.x = gelu_grad(v.x); o.y = gelu_grad(v.y); o.z = gelu_grad(v.z); o.w = gelu_grad(v.w);
   return o;
+}
+
+// GELU and its derivative together (the fused backward kernels need gelu(a) as a contraction operand and gelu'(a) for
+// the chain, of the same a): one rcp + one exp2 shared, gelu = relu(x) - |x| Phi(-|x|) from the derivative's own
+// Phi(-|x|) (A&S 7.1.26 erfc, 7.5e-8 absolute on Phi: the value is within 4e-7 of the exact-erf form for |x| < 6)
+__device__ __forceinline__ float gelu_grad_value(float x, float& val) {
+  const float z = x * 0.70710678118654752440f;
+  const float az = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float zs = z * 1.20112240878644977f;
+  const float e = __builtin_amdgcn_exp2f(-(zs * zs));  // exp(-x^2 / 2)
+  const float q = 0.5f * (p * e);                      // Phi(-|x|)
+  const float Phi = x >= 0.f ? 1.0f - q : q;
+  val = fmaf(-fabsf(x), q, fmaxf(x, 0.f));
+  return fmaf(x * 0.39894228040143267794f, e, Phi);
+}
+// v <- gelu'(v) in place; returns gelu(v)
+__device__ __forceinline__ f32x4 gelu_value_grad4(f32x4& v) {
+#ifdef MPNN_ABL_NOGELU  // timing-only ablation build: never shipped
+  return v;
+#endif
+  float a, b, c, d;
+  v.x = gelu_grad_value(v.x, a); v.y = gelu_grad_value(v.y, b);
+  v.z = gelu_grad_value(v.z, c); v.w = gelu_grad_value(v.w, d);
+  return f32x4{a, b, c, d};
 }
 
 // Gradients are tiny (the loss is divided by 2000, train.py:72) while the f16 hi/lo split only resolves 6e-8

@@ -194,6 +194,12 @@ __device__ __forceinline__ f32x4 abl_mfma(h8 a, h8 b, f32x4 c) {
   return c;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) abl_mfma(a, b, c)
+typedef _Float16 abl_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 abl_mfma4(abl_h4 a, abl_h4 b, f32x4 c) {
+  asm volatile("" ::"v"(a), "v"(b));
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, x, y, z) abl_mfma4(a, b, c)
 #endif
 
 struct BFrag {

@@ -538,14 +538,22 @@ k_wgrad_reduce(const float* __restrict__ part, int nparts, size_t stride, float*
 // fixed order.
 // ---------------------------------------------------------------------------
 constexpr int FB_WAVES = 8;
+#ifdef MPNN_ABL_FUSED_NOBARRIER  // timing-only ablation build: never shipped
+#define FB_BARRIER() FENCE()
+#else
+#define FB_BARRIER() __syncthreads()
+#endif
 constexpr int FB_LDK = 16 * 3 + 4;  // padded edge stride (halves) of the planes, as WG_LDK of k_wgrad at KTM = 3
 
 // scales[0] = max |dgsum| (float bits), scales[1] = max_k sum_o |W2[o][k]| (float bits); scales[] zeroed before.
 __global__ void __launch_bounds__(256)
 k_fused_scales(const float* __restrict__ dgsum, size_t n, const h8* __restrict__ W2T, unsigned* __restrict__ scales) {
   float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-    m = fmaxf(m, fabsf(dgsum[i]));
+  const f32x4* d4 = reinterpret_cast<const f32x4*>(dgsum);  // n is a multiple of 128
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = d4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) atomicMax(&scales[0], (unsigned)__float_as_int(m));  // a maximum: order-independent
@@ -561,6 +569,36 @@ k_fused_scales(const float* __restrict__ dgsum, size_t n, const h8* __restrict__
         for (int q = 0; q < 8; ++q) sum += fabsf((float)hi[q] + (float)lo[q]);
       }
     atomicMax(&scales[1], (unsigned)__float_as_int(sum));
+  }
+}
+
+// k_wgrad_reduce for up to three partial blocks of one workspace in ONE launch (blockIdx.y = which)
+struct ReduceJobs {
+  const float* part[3];
+  float* dW[3];
+  float* db[3];
+};
+__global__ void __launch_bounds__(256)
+k_wgrad_reduce_n(ReduceJobs jobs, int nparts, size_t stride) {
+  __shared__ float sl[16][17];
+  const float* part = jobs.part[blockIdx.y];
+  float* dW = jobs.dW[blockIdx.y];
+  float* db = jobs.db[blockIdx.y];
+  const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + el;
+  float s = 0.f;
+  if (i < WG_PART)
+    for (int w = slice; w < nparts; w += 16) s += part[(size_t)w * stride + i];
+  sl[slice][el] = s;
+  __syncthreads();
+  if (slice == 0 && i < WG_PART) {
+    float t = sl[0][el];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sl[k][el];
+    if (i < MPNN_H * MPNN_H)
+      dW[i] += t;
+    else if (db)
+      db[i - MPNN_H * MPNN_H] += t;
   }
 }
 
@@ -598,7 +636,8 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
   f32x4 accW2[MPNN_NT], accW1[MPNN_NT];
 #pragma unroll
   for (int j = 0; j < MPNN_NT; ++j) accW2[j] = accW1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 bacc = f32x4{0.f, 0.f, 0.f, 0.f};
+  __shared__ float sacc[MPNN_H];  // db2: one writer lane per word, in residue order (first touched after a barrier)
+  if (threadIdx.x < MPNN_H) sacc[threadIdx.x] = 0.f;
   float vmax = 0.f;
   // where this lane's share of a (feature tile, column tile) goes in the planes / in a B fragment
   const int frow = 16 * wave + 4 * g + (col & 3);
@@ -681,6 +720,9 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
   // addresses = a uniform residue base (scalar registers) + a 32-bit lane offset that never changes
   const unsigned tile_off = (unsigned)(wave * KT) * 64u + (unsigned)lane;  // f32x4 elements into a residue's fragments
   auto tile_of = [&](const f32x4* base, int node) {
+#ifdef MPNN_ABL_FUSED_SAMELOAD  // timing-only ablation build: never shipped
+    node = blockIdx.x;
+#endif
     return base + (size_t)__builtin_amdgcn_readfirstlane(node) * (MPNN_NT * KT * 64);
   };
   auto load_tile = [&](f32x4 (&dst)[KT], const f32x4* base, int node) {
@@ -740,15 +782,16 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
     load_tile(xe, hE, node);
     FENCE();
     // ---- phase 1: da2 of this wave's feature tile; its B fragments and planes, the planes of gelu(a1)
+    f32x4 bacc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
       f32x4 d2 = gelu_grad4(x2[c]) * (gs * w[c]);
       bacc += d2;
       publish_grad(0, c, d2 * sc1);
-      publish_act(0, c, gelu4(x1[c]));
+      publish_act(0, c, gelu_value_grad4(x1[c]));  // x1 <- gelu'(a1)
       FENCE();
     }
-    __syncthreads();  // A: stage-0 fragments and planes complete (and stage 1 of the previous residue consumed)
+    FB_BARRIER();  // A: stage-0 fragments and planes complete (and stage 1 of the previous residue consumed)
     if (accumulate) load_tile(pe, dE, node);
     FENCE();
     // ---- phase 2: dg1 = W2^T da2; da1, dP, rows; dW2 += da2 (x) gelu(a1)
@@ -756,7 +799,7 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
       f32x4 y = gemm_tile(0, c, w2h, w2l);
-      y *= gelu_grad4(x1[c]) * un1;
+      y *= x1[c] * un1;
       ps += y;
       if (DEC) y *= s[c];
       {
@@ -768,9 +811,11 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
       FENCE();
     }
     ps = column_sum4(ps);
+    bacc = column_sum4(bacc);
     if (col == 0) {
       float* pb = dP + (size_t)__builtin_amdgcn_readfirstlane(node) * MPNN_H;
       *reinterpret_cast<f32x4*>(&pb[(unsigned)(16 * wave + 4 * g)]) = ps;
+      *reinterpret_cast<f32x4*>(&sacc[16 * wave + 4 * g]) += bacc;
     }
     FENCE();
     h8 w1h[NKK], w1l[NKK];
@@ -785,7 +830,7 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
     }
     FENCE();
     contract(0, accW2);
-    __syncthreads();  // B: stage-1 fragments and planes complete (and stage 0 consumed)
+    FB_BARRIER();  // B: stage-1 fragments and planes complete (and stage 0 consumed)
     if (more) {
       load_masks(nxt);
       load_tile(x2, a2, nxt);
@@ -821,13 +866,10 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
       P[(16 * wave + 4 * g + r) * MPNN_H + 16 * j + col] = accW2[j][r] * un1;
       P[WG_PART + (16 * wave + 4 * g + r) * MPNN_H + 16 * j + col] = accW1[j][r] * un2;
     }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float v = column_sum(bacc[r]);
-    if (col == 0) {
-      P[MPNN_H * MPNN_H + 16 * wave + 4 * g + r] = v;
-      P[WG_PART + MPNN_H * MPNN_H + 16 * wave + 4 * g + r] = 0.f;
-    }
+  __syncthreads();
+  if (threadIdx.x < MPNN_H) {
+    P[MPNN_H * MPNN_H + threadIdx.x] = sacc[threadIdx.x];
+    P[WG_PART + MPNN_H * MPNN_H + threadIdx.x] = 0.f;
   }
 }
 
@@ -1017,6 +1059,9 @@ k_edge_update_bwd_fused(const f32x4* __restrict__ dy, const f32x4* __restrict__ 
   };
   const unsigned tile_off = (unsigned)(wave * KT) * 64u + (unsigned)lane;
   auto tile_of = [&](const f32x4* base, int node) {
+#ifdef MPNN_ABL_FUSED_SAMELOAD  // timing-only ablation build: never shipped
+    node = blockIdx.x;
+#endif
     return base + (size_t)__builtin_amdgcn_readfirstlane(node) * (MPNN_NT * KT * 64);
   };
   auto load_tile = [&](f32x4 (&dst)[KT], const f32x4* base, int node) {
@@ -1051,7 +1096,7 @@ k_edge_update_bwd_fused(const f32x4* __restrict__ dy, const f32x4* __restrict__ 
     }
     load_tile(t1, a1, node);
     FENCE();
-    __syncthreads();  // L
+    FB_BARRIER();  // L
     // ---- stage 0: dz, its dropout, fragments and planes; planes of gelu(a2); t2 <- gelu'(a2)
     f32x4 bacc13 = f32x4{0.f, 0.f, 0.f, 0.f}, lg = bacc13, lb = bacc13;
 #pragma unroll
@@ -1076,8 +1121,7 @@ k_edge_update_bwd_fused(const f32x4* __restrict__ dy, const f32x4* __restrict__ 
                        drop_seed, drop_thresh, inv_keep);
       bacc13 += dzd;
       publish_grad(0, c, dzd * sc[0]);
-      publish_act(0, c, gelu4(t2[c]));
-      t2[c] = gelu_grad4(t2[c]);
+      publish_act(0, c, gelu_value_grad4(t2[c]));  // t2 <- gelu'(a2)
       FENCE();
     }
     sacc_add(0, bacc13);
@@ -1087,7 +1131,7 @@ k_edge_update_bwd_fused(const f32x4* __restrict__ dy, const f32x4* __restrict__ 
     h8 wh[NKK], wl[NKK];
     load_w(W13T, wh, wl);
     FENCE();
-    __syncthreads();  // A
+    FB_BARRIER();  // A
     // ---- stage 1: dW13 += dzd (x) gelu(a2) first (the A planes are single-buffered), then da2 = (W13^T dzd) gelu'(a2),
     //      its fragments and planes, the planes of gelu(a1); t1 <- gelu'(a1)
     contract(0, acc13);
@@ -1098,15 +1142,14 @@ k_edge_update_bwd_fused(const f32x4* __restrict__ dy, const f32x4* __restrict__ 
       y *= t2[c] * un[0];
       bacc12 += y;
       publish_grad(1, c, y * sc[1]);
-      publish_act(1, c, gelu4(t1[c]));
-      t1[c] = gelu_grad4(t1[c]);
+      publish_act(1, c, gelu_value_grad4(t1[c]));  // t1 <- gelu'(a1)
       FENCE();
     }
     sacc_add(1, bacc12);
     FENCE();
     load_w(W12T, wh, wl);
     FENCE();
-    __syncthreads();  // B
+    FB_BARRIER();  // B
     // ---- stage 2: dW12 += da2 (x) gelu(a1); da1 = (W12^T da2) gelu'(a1): rows, dP, fragments (stage 0's buffer)
     contract(1, acc12);
     f32x4 ps = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1131,7 +1174,7 @@ k_edge_update_bwd_fused(const f32x4* __restrict__ dy, const f32x4* __restrict__ 
     FENCE();
     load_w(W11bT, wh, wl);
     FENCE();
-    __syncthreads();  // C
+    FB_BARRIER();  // C
     // ---- stage 3: dE = dz + W11b^T da1; dW11b += da1 (x) e
     {
       f32x4* dst = const_cast<f32x4*>(tile_of(dE, node));
@@ -1318,7 +1361,7 @@ extern "C" int mpnn_message_bwd_fused(int dec, const float* dgsum, const float* 
     mpnn_set_error("mpnn_message_bwd_fused: hipMemsetAsync failed");
     return 1;
   }
-  hipLaunchKernelGGL(k_fused_scales, dim3(64), dim3(256), 0, st, dgsum, (size_t)N * MPNN_H, (const h8*)W2T_packed,
+  hipLaunchKernelGGL(k_fused_scales, dim3(256), dim3(256), 0, st, dgsum, (size_t)N * MPNN_H, (const h8*)W2T_packed,
                      scales);
   if (dec) {
     if (KT == 1) MPNN_FB_LAUNCH(1, true); else if (KT == 2) MPNN_FB_LAUNCH(2, true); else MPNN_FB_LAUNCH(3, true);
@@ -1326,10 +1369,8 @@ extern "C" int mpnn_message_bwd_fused(int dec, const float* dgsum, const float* 
     if (KT == 1) MPNN_FB_LAUNCH(1, false); else if (KT == 2) MPNN_FB_LAUNCH(2, false); else MPNN_FB_LAUNCH(3, false);
   }
 #undef MPNN_FB_LAUNCH
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((WG_PART + 15) / 16), dim3(256), 0, st, workspace, nwg, (size_t)(2 * WG_PART),
-                     dW2, db2);
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((WG_PART + 15) / 16), dim3(256), 0, st, workspace + WG_PART, nwg,
-                     (size_t)(2 * WG_PART), dW1b, (float*)nullptr);
+  ReduceJobs jobs = {{workspace, workspace + WG_PART, nullptr}, {dW2, dW1b, nullptr}, {db2, nullptr, nullptr}};
+  hipLaunchKernelGGL(k_wgrad_reduce_n, dim3((WG_PART + 15) / 16, 2), dim3(256), 0, st, jobs, nwg, (size_t)(2 * WG_PART));
   MPNN_LAUNCH_CHECK();
 }
 
@@ -1393,9 +1434,8 @@ extern "C" int mpnn_enc_edge_update_bwd_fused(const float* dy_frag, const float*
                      workspace, (unsigned*)dE_absmax, (unsigned*)da1_absmax, thresh, (unsigned)drop_seed, inv_keep)
   if (KT == 1) MPNN_EU_LAUNCH(1); else if (KT == 2) MPNN_EU_LAUNCH(2); else MPNN_EU_LAUNCH(3);
 #undef MPNN_EU_LAUNCH
-  const dim3 rg((WG_PART + 15) / 16), rb(256);
-  hipLaunchKernelGGL(k_wgrad_reduce, rg, rb, 0, st, workspace, nwg, (size_t)EU_PART, dW13, db13);
-  hipLaunchKernelGGL(k_wgrad_reduce, rg, rb, 0, st, workspace + WG_PART, nwg, (size_t)EU_PART, dW12, db12);
+  ReduceJobs jobs = {{workspace, workspace + WG_PART, nullptr}, {dW13, dW12, nullptr}, {db13, db12, nullptr}};
+  hipLaunchKernelGGL(k_wgrad_reduce_n, dim3((WG_PART + 15) / 16, 2), dim3(256), 0, st, jobs, nwg, (size_t)EU_PART);
   launch_partials_reduce(workspace + 2 * WG_PART, nwg, EU_PART, 2 * MPNN_H, dln, 1, st);
   MPNN_LAUNCH_CHECK();
 }
