@@ -278,11 +278,13 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
     _lib.set_profiler(None)
     kern = {n: round(sum(e0.elapsed_time(e1) for e0, e1 in evs) / 3, 3) for n, evs in sorted(prof.items())}
     hip_ms = sum(kern.values())
-    # HBM bytes this design moves per residue and step (confirmed per kernel by the PMC passes in
-    # profiles/r01_pmc_traffic_train.txt): in units of one residue's fragment tensor F = 8 * ceil(K/16) KiB,
-    # encoder layer 36 F, decoder layer 14 F, featurizer 20 F  =>  170 F for the 3 + 3 layer model
+    # HBM bytes this design moves per residue and step (per kernel confirmed by the PMC passes in
+    # profiles/r03_pmc_traffic_train.txt): in units of one residue's fragment tensor F = 8 * ceil(K/16) KiB.
+    #   K <= 48 (fused backward kernels): encoder layer 25 F (message forward 3, edge-update forward 6, fused edge-update
+    #   backward 6 + W11b contraction 2 + gather 1, fused message backward 6 + gather 1), decoder layer 9.67 F,
+    #   featurizer 20 F  =>  124 F for the 3 + 3 layer model;  K > 48 (unfused): 36 / 14 / 20  =>  170 F
     frag = 8 * ((K + 15) // 16) * 1024
-    step_bytes = 170 * frag * B * L
+    step_bytes = (124 if K <= 48 else 170) * frag * B * L
     tbps = step_bytes / (elapsed / steps) / 1e12
     return {**(ranks or {}),
             "metric": "residues/sec (train step: fwd + bwd + AdamW) at L=512,k=48",
@@ -294,9 +296,10 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
                                    "all-reduce per step", "global_batch": B * world},
             "roofline": {"bound": "hbm", "achieved": round(tbps * 1e3, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(tbps / 8.0, 4), "bytes_per_step": step_bytes,
-                         "note": "whole step: saved activations and per-edge gradients are written once and re-read "
-                                 "by the backward and weight-gradient passes; the edge backward kernels run at "
-                                 "4.3-4.5 TB/s, the weight-gradient pass at 3.6 TB/s (PMC-confirmed bytes)"},
+                         "note": "whole step, design bytes (124 fragment tensors per residue at K <= 48: the fused "
+                                 "backward kernels keep da2 / dz in the workgroup and read each saved tensor once); the "
+                                 "fused backward kernels themselves are LDS- / issue-bound in lock-step (2.3-3.5 TB/s), "
+                                 "the forward-with-saves kernels and the weight-gradient passes run at 4-5 TB/s"},
             "final_loss": round(float(loss), 6),
             "hip_kernels_ms_per_step": kern, "hip_kernels_total_ms": round(hip_ms, 3),
             "note": "forward, backward and weight gradients of the featurizer, edge and node stages, the output head, "
