@@ -597,3 +597,80 @@ def test_backward_is_bit_reproducible():
         after.append({n: p.detach().clone() for n, p in model.named_parameters()})
     for n in after[0]:
         assert torch.equal(after[0][n], after[1][n]), n
+
+
+def test_fused_backward_kernels_match_the_unfused_path():
+    """mpnn_message_bwd_fused / mpnn_enc_edge_update_bwd_fused (K <= 48: chain + weight-gradient contractions in one
+    kernel, operand scales from bounds) against mpnn_message_bwd / mpnn_enc_edge_update_bwd + mpnn_edge_wgrad (exact
+    per-tensor maxima) on one model and batch: same loss, every gradient within 2e-5 relative L2 (both are fp32-class
+    split-f16 evaluations of the same sums in different orders), and the fused entry points are the ones that ran."""
+    from mpnn_amd import _lib, training
+    from mpnn_amd.synthetic import synthetic_batch
+
+    kw = dict(k_neighbors=48)
+    b = synthetic_batch(B=3, L=96, seed=21, lengths=[96, 80, 57], n_chains=2, design_fraction=0.6)
+    model = build(kw)
+    seen = {}
+    saved = (training.FUSED_MSG_BWD, training.FUSED_UPD_BWD)
+    try:
+        res = {}
+        for tag, flag in (("fused", True), ("unfused", False)):
+            training.FUSED_MSG_BWD = training.FUSED_UPD_BWD = flag
+            prof = {}
+            _lib.set_profiler(prof)
+            res[tag] = hip_loss_and_grads(model, b)
+            _lib.set_profiler(None)
+            seen[tag] = set(prof)
+    finally:
+        _lib.set_profiler(None)
+        training.FUSED_MSG_BWD, training.FUSED_UPD_BWD = saved
+    assert {"mpnn_message_bwd_fused", "mpnn_enc_edge_update_bwd_fused"} <= seen["fused"]
+    assert not ({"mpnn_message_bwd", "mpnn_enc_edge_update_bwd"} & seen["fused"])
+    assert {"mpnn_message_bwd", "mpnn_enc_edge_update_bwd"} <= seen["unfused"]
+    assert not ({"mpnn_message_bwd_fused", "mpnn_enc_edge_update_bwd_fused"} & seen["unfused"])
+    (lf, _, gf), (lu, _, gu) = res["fused"], res["unfused"]
+    assert lf == lu                      # the forward pass is the same kernels
+    total = sum(float(v.double().norm() ** 2) for v in gu.values()) ** 0.5
+    for n in gu:
+        err = float((gf[n].double() - gu[n].double()).norm())
+        assert err <= 2e-5 * float(gu[n].double().norm()) + 1e-7 * total, (n, err, float(gu[n].double().norm()))
+
+
+def test_fused_edge_update_backward_scale_bound_holds_for_extreme_layernorms():
+    """The fused edge-update backward scales its f16 operand splits from BOUNDS (13.3 rstd_max max|ln_w| max|dy|, then
+    1.13 ||W^T|| per GEMM).  A bound that were too small would overflow the f16 range (inf / NaN gradients), one that is
+    far too large would starve the lo halves: near-constant edge rows (rstd close to 1 / sqrt(eps)) and large LayerNorm
+    weights must still give the unfused path's gradients."""
+    from mpnn_amd import engine, training
+
+    torch.manual_seed(5)
+    d = "cuda"
+    B, L, K = 1, 40, 30
+    N = B * L
+    E_idx = torch.stack([torch.stack([torch.randperm(L)[:K] for _ in range(L)]) for _ in range(B)]).to(d)
+    idx32 = torch.zeros(N, 32, dtype=torch.int32, device=d)
+    idx32[:, :K] = E_idx.reshape(N, K).to(torch.int32)
+    g = training.Graph(E_idx, idx32.reshape(-1).contiguous(), torch.ones(N, device=d), None, K)
+    mk = lambda *s, sc=1.0: (sc * torch.randn(*s, device=d))
+    base = dict(hE=mk(N, K, 128, sc=1e-3) + 0.7, P=mk(N, 128, sc=1e-3), Q=mk(N, 128, sc=1e-3),
+                W11b=mk(128, 128, sc=0.02), W12=mk(128, 128, sc=0.02), b12=mk(128, sc=0.01), W13=mk(128, 128, sc=0.02),
+                b13=mk(128, sc=0.01), lnw=mk(128) * 20.0, lnb=mk(128, sc=0.1))
+    upstream = engine.edges_from_natural(torch.randn(N, K, 128, device=d) * 3e-5, N, K)
+    saved = training.FUSED_UPD_BWD
+    out = {}
+    try:
+        for flag in (True, False):
+            training.FUSED_UPD_BWD = flag
+            training._ZEROS.reset(torch.device(d, torch.cuda.current_device()))
+            p = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+            hE = training.FromNaturalFn.apply(g, p["hE"])
+            y = training.EdgeUpdateFn.apply(g, training.GradSlot(), training.GradSlot(), 0.0, 0, hE, p["P"], p["Q"], p["W11b"],
+                                            p["W12"], p["b12"], p["W13"], p["b13"], p["lnw"], p["lnb"])
+            y.backward(upstream)
+            out[flag] = {k: v.grad.clone() for k, v in p.items()}
+    finally:
+        training.FUSED_UPD_BWD = saved
+    for k in base:
+        a, w = out[True][k].double(), out[False][k].double()
+        assert bool(torch.isfinite(a).all()), k
+        assert float((a - w).norm()) <= 1e-4 * float(w.norm()) + 1e-12, (k, float((a - w).norm()), float(w.norm()))
