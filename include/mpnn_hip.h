@@ -672,6 +672,16 @@ int mpnn_assemble_batch(const float* X_cat, const uint8_t* S_cat, const int32_t*
                         float* mask, float* chain_M, int64_t* residue_idx, int64_t* chain_encoding_all,
                         int32_t* lengths, void* stream);
 
+/* mpnn_assemble_batch with the chain order of every structure chosen PER BATCH, as featurize does (it shuffles the
+ * chains of an entry every time the entry is drawn, src/mpnn/data/data_utils.py:88; chain numbers and the +100 jumps of
+ * residue_idx then follow the new order, :117-120).  Row b is the concatenation of the shard's residue ranges
+ * [seg_src[k], seg_src[k] + seg_len[k]) for k in [seg_ptr[b], seg_ptr[b + 1]) - the structure's chains in the order
+ * wanted (device arrays; a few integers per structure, built on the host per batch).  Outputs as mpnn_assemble_batch. */
+int mpnn_assemble_batch_ordered(const float* X_cat, const uint8_t* S_cat, const uint8_t* designed_cat,
+                                const int32_t* seg_ptr, const int64_t* seg_src, const int32_t* seg_len, int B,
+                                int L_max, float* X, int64_t* S, float* mask, float* chain_M, int64_t* residue_idx,
+                                int64_t* chain_encoding_all, int32_t* lengths, void* stream);
+
 /* mask_self [B,L,L] f32 of featurize() (data_utils.py:61,119): 0 where both residues belong to the same chain, 1
  * elsewhere (padding included). */
 int mpnn_mask_self(const int64_t* chain_encoding_all, int B, int L, float* mask_self, void* stream);

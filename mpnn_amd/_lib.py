@@ -87,6 +87,7 @@ SIGNATURES = {
     "mpnn_logits_log_softmax_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
     "mpnn_loss_smoothed": [_P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _P, _I, _P],
     "mpnn_assemble_batch": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mpnn_assemble_batch_ordered": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "mpnn_mask_self": [_P, _I, _I, _P, _P],
     "mpnn_node_wgrad": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P],
     "mpnn_gather_indexed": [_P, _P, ctypes.c_longlong, _I, ctypes.c_longlong, _I, _P, _I, _I, _P],

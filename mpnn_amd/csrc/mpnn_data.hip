@@ -54,6 +54,61 @@ k_assemble_batch(const f32x4* __restrict__ Xc, const uint8_t* __restrict__ Sc, c
   chain_enc[slot] = ce;
 }
 
+// The same with the chain order of every structure given PER BATCH (featurize reshuffles the chains of an entry each
+// time it is drawn, data_utils.py:88): row b is the concatenation of the segments seg_src / seg_len[seg_ptr[b] ..
+// seg_ptr[b + 1]) of the shard, in that order; chain numbers and the +100 residue-index jumps follow the NEW order
+// (:117-120).  A thread walks its row's segment list (a handful of chains).
+__global__ void __launch_bounds__(256)
+k_assemble_batch_ordered(const f32x4* __restrict__ Xc, const uint8_t* __restrict__ Sc,
+                         const uint8_t* __restrict__ designedc, const int32_t* __restrict__ seg_ptr,
+                         const long long* __restrict__ seg_src, const int32_t* __restrict__ seg_len, int B, int L,
+                         f32x4* __restrict__ X, long long* __restrict__ S, float* __restrict__ mask,
+                         float* __restrict__ chain_M, long long* __restrict__ residue_idx,
+                         long long* __restrict__ chain_enc, int32_t* __restrict__ lengths) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= B * L) return;
+  const int b = slot / L, pos = slot - b * L;
+  const int k0 = seg_ptr[b], k1 = seg_ptr[b + 1];
+  long long src = -1;
+  int c = 0, cum = 0;
+  for (int k = k0; k < k1; ++k) {
+    const int n = seg_len[k];
+    if (src < 0 && pos < cum + n) {
+      src = seg_src[k] + (pos - cum);
+      c = k - k0 + 1;
+    }
+    cum += n;
+  }
+  if (pos == 0) lengths[b] = cum;
+  f32x4 x[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  long long s = 0, ridx = -100, ce = 0;
+  float m = 0.f, cm = 0.f;
+  if (src >= 0) {
+    bool finite = true;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      x[q] = Xc[src * 3 + q];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        finite = finite && isfinite(x[q][r]);
+        if (isnan(x[q][r])) x[q][r] = 0.f;
+      }
+    }
+    m = finite ? 1.f : 0.f;
+    s = Sc[src];
+    ce = c;
+    ridx = 100LL * (c - 1) + pos;
+    cm = designedc[src] ? 1.f : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) X[(size_t)slot * 3 + q] = x[q];
+  S[slot] = s;
+  mask[slot] = m;
+  chain_M[slot] = cm;
+  residue_idx[slot] = ridx;
+  chain_enc[slot] = ce;
+}
+
 // mask_self[b,i,j] = 0 where i and j are residues of the same chain, 1 elsewhere (padding included) (:61,119)
 __global__ void __launch_bounds__(256)
 k_mask_self(const long long* __restrict__ chain_enc, int B, int L, float* __restrict__ out) {
@@ -132,6 +187,23 @@ extern "C" int mpnn_assemble_batch(const float* X_cat, const uint8_t* S_cat, con
   const int slots = B * L_max;
   hipLaunchKernelGGL(k_assemble_batch, dim3((slots + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      (const f32x4*)X_cat, S_cat, chain_cat, designed_cat, (const long long*)offsets, protein_ids, B, L_max,
+                     (f32x4*)X, (long long*)S, mask, chain_M, (long long*)residue_idx, (long long*)chain_encoding_all,
+                     lengths);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_assemble_batch_ordered(const float* X_cat, const uint8_t* S_cat, const uint8_t* designed_cat,
+                                           const int32_t* seg_ptr, const int64_t* seg_src, const int32_t* seg_len, int B,
+                                           int L_max, float* X, int64_t* S, float* mask, float* chain_M,
+                                           int64_t* residue_idx, int64_t* chain_encoding_all, int32_t* lengths,
+                                           void* stream) {
+  MPNN_CHECK_ARG(X_cat && S_cat && designed_cat && seg_ptr && seg_src && seg_len && X && S && mask && chain_M &&
+                     residue_idx && chain_encoding_all && lengths,
+                 "mpnn_assemble_batch_ordered: null pointer");
+  MPNN_CHECK_ARG(B > 0 && L_max > 0 && (long long)B * L_max < (1LL << 31), "mpnn_assemble_batch_ordered: bad sizes");
+  const int slots = B * L_max;
+  hipLaunchKernelGGL(k_assemble_batch_ordered, dim3((slots + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const f32x4*)X_cat, S_cat, designed_cat, seg_ptr, (const long long*)seg_src, seg_len, B, L_max,
                      (f32x4*)X, (long long*)S, mask, chain_M, (long long*)residue_idx, (long long*)chain_encoding_all,
                      lengths);
   MPNN_LAUNCH_CHECK();

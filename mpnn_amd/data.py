@@ -7,11 +7,11 @@ that host work is the bottleneck of the loop.  Here the entries are flattened ON
 per-residue tensors + offsets) that lives in HBM, and a batch is one kernel launch (`mpnn_assemble_batch`) that writes
 the same eight outputs `featurize` returns, in the dtypes the model takes.
 
-Difference from the reference (documented, not hidden): `featurize` reshuffles the chain order of every entry on EVERY
-batch (data_utils.py:88), so `residue_idx` offsets and chain numbers change from epoch to epoch; a `StructureShard`
-fixes the chain order once, when it is built (`flatten_entry`).  To keep that augmentation rebuild the shard per epoch
-(`StructureShard.from_entries(entries, rng)`, host work of a few ms per thousand entries) - `assemble` itself never
-permutes chains.
+`featurize` reshuffles the chain order of every entry on EVERY batch (data_utils.py:88), so `residue_idx` offsets and
+chain numbers change from draw to draw.  `assemble(ids, shuffle_chains=True, rng=...)` does the same on the device
+(`mpnn_assemble_batch_ordered`: the host draws one permutation of a handful of chain segments per structure, the kernel
+lays the residues out in that order); build the shard with `shuffle=False` and pass the `random.Random` the reference
+would have used to get its exact permutations.  Without `shuffle_chains` the order stored in the shard is kept.
 
 Host code in this file is plumbing (numpy over Python dicts, executed once per dataset); the per-batch path is the HIP
 kernel and has no CPU fallback.
@@ -77,7 +77,17 @@ class StructureShard:
 
     def __init__(self, X, S, chain, designed, offsets):
         self.X, self.S, self.chain, self.designed, self.offsets = X, S, chain, designed, offsets
-        self.lengths = np.diff(offsets.cpu().numpy()).astype(np.int64)   # host copy: batch shapes are host decisions
+        off = offsets.cpu().numpy()
+        self.lengths = np.diff(off).astype(np.int64)   # host copy: batch shapes are host decisions
+        # chain segments of every structure (host copies, like the lengths): starts where the stored chain number changes
+        ch = chain.cpu().numpy()
+        cut = np.flatnonzero(np.diff(ch) != 0) + 1
+        starts = np.unique(np.concatenate([off[:-1], cut]))
+        starts = starts[starts < ch.shape[0]] if ch.shape[0] else starts[:0]
+        self._seg_start = starts.astype(np.int64)
+        self._seg_len = np.diff(np.concatenate([starts, [ch.shape[0]]])).astype(np.int32)
+        self._seg_of = np.searchsorted(starts, off[:-1], side="left").astype(np.int64)   # first segment of a structure
+        self._seg_cnt = np.diff(np.concatenate([self._seg_of, [starts.shape[0]]])).astype(np.int64)
 
     @classmethod
     def from_entries(cls, entries, rng: _random.Random | None = None, shuffle: bool = True):
@@ -102,10 +112,22 @@ class StructureShard:
     def from_state(cls, state):
         return cls(*(state[k] for k in cls.FIELDS))
 
-    def assemble(self, ids, with_mask_self: bool = False):
+    def chain_orders(self, ids, rng=None):
+        """One permutation of its chain segments per structure in `ids`, drawn like data_utils.py:88
+        (`random.shuffle(all_chains)`; `rng`: a `random.Random`, default the global module like the reference)."""
+        out = []
+        for i in np.asarray(ids, dtype=np.int64).reshape(-1):
+            order = list(range(int(self._seg_cnt[i])))
+            (rng or _random).shuffle(order)
+            out.append(order)
+        return out
+
+    def assemble(self, ids, with_mask_self: bool = False, shuffle_chains: bool = False, rng=None, chain_orders=None):
         """The eight outputs of `featurize` (data_utils.py:183) for the structures `ids`, padded to the longest:
         X [B,L,4,3] f32, S i64, mask f32, lengths i32 (device tensor), chain_M f32, residue_idx i64, mask_self f32
-        [B,L,L] (None unless asked: it is O(L^2) and only the interface loss reads it), chain_encoding_all i64."""
+        [B,L,L] (None unless asked: it is O(L^2) and only the interface loss reads it), chain_encoding_all i64.
+        `shuffle_chains=True` (or explicit `chain_orders`, one permutation of range(n_chains) per id) reorders the
+        chains of every structure for THIS batch as `featurize` does (data_utils.py:88)."""
         dev = self.X.device
         if dev.type != "cuda":
             raise RuntimeError("StructureShard.assemble runs on the GPU: move the shard with .to('cuda') first "
@@ -123,11 +145,35 @@ class StructureShard:
         chain_enc = torch.empty(B, L, device=dev, dtype=torch.int64)
         lengths = torch.empty(B, device=dev, dtype=torch.int32)
         mask_self = None
+        if shuffle_chains and chain_orders is None:
+            chain_orders = self.chain_orders(ids_host, rng)
         with torch.cuda.device(dev):  # launches go to the current device's stream
             st = stream_ptr()
-            call("mpnn_assemble_batch", ptr(self.X), ptr(self.S), ptr(self.chain), ptr(self.designed), ptr(self.offsets),
-                 ptr(ids_dev), B, L, ptr(X), ptr(S), ptr(mask), ptr(chain_M), ptr(residue_idx), ptr(chain_enc),
-                 ptr(lengths), st)
+            if chain_orders is not None:
+                if len(chain_orders) != B:
+                    raise ValueError("chain_orders needs one permutation per id")
+                seg_ptr = np.zeros(B + 1, np.int32)
+                src, ln = [], []
+                for r, (i, order) in enumerate(zip(ids_host, chain_orders)):
+                    order = np.asarray(order, dtype=np.int64)
+                    if sorted(order.tolist()) != list(range(int(self._seg_cnt[i]))):
+                        raise ValueError(f"chain order of structure {int(i)} is not a permutation of its "
+                                         f"{int(self._seg_cnt[i])} chains")
+                    k = self._seg_of[i] + order
+                    src.append(self._seg_start[k])
+                    ln.append(self._seg_len[k])
+                    seg_ptr[r + 1] = seg_ptr[r] + order.shape[0]
+                # one small pinned upload per batch: [seg_src (i64) | seg_len (i32) | seg_ptr (i32)]
+                seg_src = torch.from_numpy(np.concatenate(src)).to(dev, non_blocking=True)
+                seg_len = torch.from_numpy(np.concatenate(ln)).to(dev, non_blocking=True)
+                seg_ptr_d = torch.from_numpy(seg_ptr).to(dev, non_blocking=True)
+                call("mpnn_assemble_batch_ordered", ptr(self.X), ptr(self.S), ptr(self.designed), ptr(seg_ptr_d),
+                     ptr(seg_src), ptr(seg_len), B, L, ptr(X), ptr(S), ptr(mask), ptr(chain_M), ptr(residue_idx),
+                     ptr(chain_enc), ptr(lengths), st)
+            else:
+                call("mpnn_assemble_batch", ptr(self.X), ptr(self.S), ptr(self.chain), ptr(self.designed),
+                     ptr(self.offsets), ptr(ids_dev), B, L, ptr(X), ptr(S), ptr(mask), ptr(chain_M), ptr(residue_idx),
+                     ptr(chain_enc), ptr(lengths), st)
             if with_mask_self:
                 mask_self = torch.empty(B, L, L, device=dev, dtype=torch.float32)
                 call("mpnn_mask_self", ptr(chain_enc), B, L, ptr(mask_self), st)

@@ -110,3 +110,27 @@ def test_training_over_assembled_batches_of_changing_shape():
     after = held_out_loss()
     assert all(torch.isfinite(p).all() for p in model.parameters())
     assert np.isfinite(after) and after < before, (before, after)
+
+
+@pytest.mark.parametrize("ids", [[0], [1, 5, 2], list(range(12)), [7, 7, 3]])
+def test_per_batch_chain_shuffle_equals_featurize(ids):
+    """featurize shuffles the chain order of an entry EVERY time it is drawn (data_utils.py:88): a shard built in the
+    unshuffled order + assemble(shuffle_chains=True, rng) lays the chains out as the reference would with the same
+    generator - chain numbers, the +100 residue-index jumps, designed flags and coordinates bit for bit."""
+    entries = synthetic_entries(12, seed=21)
+    shard = StructureShard.from_entries(entries, shuffle=False).to("cuda")
+    for draw in range(3):                               # the same structures come out in a new order on every draw
+        want = fo.featurize([entries[i] for i in ids], rng=random.Random(500 + draw), shuffle=True)
+        got = shard.assemble(ids, with_mask_self=True, shuffle_chains=True, rng=random.Random(500 + draw))
+        torch.cuda.synchronize()
+        for name, w, g in zip(NAMES, want, got):
+            g = g.cpu().numpy()
+            assert g.dtype == w.dtype and g.shape == w.shape, name
+            assert np.array_equal(g, w, equal_nan=True), f"draw {draw}, {name}: {(g != w).sum()} entries differ"
+    # explicit orders: the identity permutation is the stored order
+    same = shard.assemble(ids, chain_orders=[list(range(int(shard._seg_cnt[i]))) for i in ids])
+    plain = shard.assemble(ids)
+    for a, b in zip(same, plain):
+        assert a is None and b is None or torch.equal(a, b)
+    with pytest.raises(ValueError):
+        shard.assemble(ids, chain_orders=[[0, 0]] * len(ids))
