@@ -556,7 +556,12 @@ k_fused_scales(const float* __restrict__ dgsum, size_t n, const h8* __restrict__
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(&scales[0], (unsigned)__float_as_int(m));  // a maximum: order-independent
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  // one atomic per workgroup (a thousand waves on one address serialise in L2); a maximum: order-independent
+  if (threadIdx.x == 0)
+    atomicMax(&scales[0], (unsigned)__float_as_int(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
   if (blockIdx.x == 0 && threadIdx.x < MPNN_H) {
     // row `col` of output tile `to` of W2^T lives in lanes col, 16 + col, 32 + col, 48 + col of every k-step
     const int to = threadIdx.x >> 4, col = threadIdx.x & 15;
