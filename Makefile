@@ -52,7 +52,16 @@ check-switches:
 	@echo "mpnn_edge.hip -DMPNN_STAMP"; $(HIPCC) $(HIPFLAGS) -DMPNN_STAMP -c $(CSRC)/mpnn_edge.hip -o /dev/null
 	@echo "check-switches: all switch builds compile"
 
-.PHONY: all clean check-switches
+# Wait states around the inline-asm VALU instructions (hipcc pads none for them) and the operand each v_fma_mix reads:
+# tools/hazard_scan.py over the final assembly of every source that holds asm, in both precisions.
+check-hazards:
+	@set -e; for f in edge node edge_bwd node_bwd loss; do python3 tools/hazard_scan.py $(CSRC)/mpnn_$$f.hip | tail -1; done
+	@python3 tools/hazard_scan.py $(CSRC)/mpnn_featurizer.hip -ffp-contract=off -fno-slp-vectorize | tail -1
+	@set -e; for f in edge node; do python3 tools/hazard_scan.py $(CSRC)/mpnn_$$f.hip -DMPNN_FAST | tail -1; done
+	@python3 tools/hazard_scan.py $(CSRC)/mpnn_featurizer.hip -DMPNN_FAST -ffp-contract=off -fno-slp-vectorize | tail -1
+	@echo "check-hazards: no findings"
+
+.PHONY: all clean check-switches check-hazards
 
 $(CSRC)/mpnn_node.o: $(CSRC)/mpnn_node.hip $(CSRC)/mpnn_common.h $(CSRC)/mpnn_ablation.h $(CSRC)/mpnn_sample.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

@@ -80,8 +80,12 @@ __device__ __forceinline__ float gelu(float x) {
   // MFMAs (tools/ubench/coissue.hip) against 4.2 for a plain v_fma_f32.  x has already been read by the v_med3 above,
   // so no MFMA -> VALU wait state is pending on it; the v_max between v_exp and the v_fma covers the one wait state a
   // transcendental's result needs.
-  float r, o;
-  asm("v_max_f32 %0, 0, %2\n\tv_fma_f32 %1, -|%2|, %3, %0" : "=&v"(r), "=v"(o) : "v"(x), "v"(e));
+  // Both results are written IN PLACE over values hipcc's own instructions produced (the clamped |x| and e, dead from
+  // here on): an asm statement's fresh destination register could be one a just-issued MFMA still reads as its C
+  // operand or writes as its result, and hipcc pads those wait states only for instructions it selects itself
+  // (tools/hazard_scan.py).  A register that held a live value up to here cannot be in either state.
+  float r = a, o = e;
+  asm("v_max_f32 %0, 0, %2\n\tv_fma_f32 %1, -|%2|, %1, %0" : "+v"(r), "+v"(o) : "v"(x));
   return o;
 }
 
@@ -215,33 +219,37 @@ struct BFrag {
 // states only for instructions it can see).
 typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// f16-products mode: ONE rounding per operand, by gfx950's packed round-to-nearest-even conversion.  Unlike
-// v_cvt_pkrtz (which truncates and therefore SATURATES at 65504) it overflows to +-inf from |x| >= 65520 on, so an
-// out-of-range activation poisons the log-probs and trips the wrapper's finiteness check exactly as in the fp32-class
-// path - the reduced-precision mode cannot return silently wrong finite numbers either.
-__device__ __forceinline__ unsigned cvt_pk_f16_rne(float lo_half, float hi_half) {
-  unsigned r;
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo_half), "v"(hi_half));
-  return r;
+// f16-products mode: ONE rounding per operand, by gfx950's packed round-to-nearest-even conversion
+// (v_cvt_pk_f16_f32).  Unlike v_cvt_pkrtz (which truncates and therefore SATURATES at 65504) it overflows to +-inf
+// from |x| >= 65520 on, so an out-of-range activation poisons the log-probs and trips the wrapper's finiteness check
+// exactly as in the fp32-class path - the reduced-precision mode cannot return silently wrong finite numbers either.
+// The instruction is left to hipcc's own selection (a vector fptrunc), NOT written as inline asm: an asm statement
+// gets none of the wait states the hazard recogniser pads, and a conversion scheduled directly behind the v_exp_f32
+// that produced its operand (the featurizer's RBFs; gfx950 needs one wait state between a transcendental and the
+// VALU instruction that reads its result) converted the STALE register - k_neighbors > 48 in f16 mode was wrong by
+// O(1) on two of the four edge tiles until round 3's fuzz sweep caught it (tests/test_gpu_parity.py holds the case).
+typedef float f32x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ h8 f16_rne8(const float (&v)[8]) {
+  return __builtin_convertvector((f32x8_t){v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}, h8);
 }
 
 __device__ __forceinline__ void split_pair(const f32x4 a, const f32x4 b, BFrag& o) {
   const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #if defined(MPNN_FAST)
-  u32x4 hi;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) hi[j] = cvt_pk_f16_rne(v[2 * j], v[2 * j + 1]);
-  asm("s_nop 1" : "+v"(hi));  // (asm results feed MFMAs: the wait states hipcc cannot see, as below)
-  o.hi = __builtin_bit_cast(h8, hi);
+  o.hi = f16_rne8(v);
 #else
   u32x4 hi, lo;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     hi[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2 * j], v[2 * j + 1]));
-    unsigned l;
-    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=&v"(l) : "v"(hi[j]), "v"(v[2 * j]));
+    // in place over the register of v[2j] (no fresh destination for an asm statement: see gelu above); where the
+    // caller still needs the value hipcc copies it first, with an instruction of its own.  The tied operand stays a
+    // FLOAT: tied to __builtin_bit_cast(unsigned, <element 2 of a vector>) this hipcc hands the asm element 0
+    // (reproducer in DESIGN.md section 0b; the gradient tests catch it at once).
+    float l = v[2 * j];
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi[j]));
     asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi[j]), "v"(v[2 * j + 1]));
-    lo[j] = l;
+    lo[j] = __builtin_bit_cast(unsigned, l);
   }
   // hipcc pads no hazard behind an asm statement: two wait states between the last v_fma_mix write and an MFMA that
   // reads the fragment; tying the nop to the whole register tuple also orders it between the two

@@ -353,8 +353,10 @@ __device__ __forceinline__ void split4(const f32x4 x, h4& hi, h4& lo) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     h[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x[2 * j], x[2 * j + 1]));
-    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=&v"(l[j]) : "v"(h[j]), "v"(x[2 * j]));
-    asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l[j]) : "v"(h[j]), "v"(x[2 * j + 1]));
+    float t = x[2 * j];  // lo in place over x[2j], tied as a float (split_pair in mpnn_common.h says why)
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(t) : "v"(h[j]));
+    asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t) : "v"(h[j]), "v"(x[2 * j + 1]));
+    l[j] = __builtin_bit_cast(unsigned, t);
   }
   typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
   hi = __builtin_bit_cast(h4, (u32x2_t){h[0], h[1]});

@@ -155,13 +155,9 @@ __global__ void k_probe(const float* __restrict__ x, int n, int mode, float* __r
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = gelu(v[j]);
   } else if (mode == 2) {
+    const h8 h = f16_rne8(v);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned p = cvt_pk_f16_rne(v[2 * j], v[2 * j + 1]);
-      const fp16x2_t h = __builtin_bit_cast(fp16x2_t, p);
-      v[2 * j] = (float)h[0];
-      v[2 * j + 1] = (float)h[1];
-    }
+    for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
   } else {
     BFrag b;
     split_pair(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, b);
