@@ -433,6 +433,22 @@ int mpnn_node_update_bwd(const float* dY, const float* dPQ_blocks, const float* 
 int mpnn_pack_blocks(const float* const* blocks, const int* ld, const int* transposed, int n, float* packed,
                      void* stream);
 
+/* The decoder's sequence term in training (model_utils.py:478-483: h_S = W_s(S) is concatenated into the decoder
+ * input, i.e. enters the third 128-column block W1c of the layer's W1 [128, 512]).  With TS = W_s W1c^T
+ * ([n_letters, 128]) the term of residue n is the row TS[S[n]]:
+ *   mpnn_seq_table      TS[l][o] = sum_i W_s[l][i] W1c[o * ld_w1c + i]        (W_s [n_letters, 128] row-major)
+ *   mpnn_add_table_rows A[n][:] = A0[n][:] + TS[S[n]][:]                        (rows of 128; S outside [0, n_letters):
+ *                                                                                nothing added)
+ *   mpnn_seq_table_bwd  dW_s[l][i] = sum_o dTS[l][o] W1c[o][i],  dW1c[o][i] = sum_l dTS[l][o] W_s[l][i]   (both
+ *                       overwritten, row-major 128-wide), dTS given TRANSPOSED as dTS_t[o * ld_dts + l] - the form
+ *                       mpnn_node_wgrad leaves when it contracts the rows' gradient with one-hot rows of S.
+ * Plain fp32 FMAs in a fixed order (gradient-sized operands: no f16 splitting, no scaling, bit-reproducible). */
+int mpnn_seq_table(const float* Ws, const float* W1c, int ld_w1c, int n_letters, float* TS, void* stream);
+int mpnn_add_table_rows(const float* A0, const float* TS, const int64_t* S, int n_letters, int n_rows, float* A,
+                        void* stream);
+int mpnn_seq_table_bwd(const float* dTS_t, int ld_dts, const float* Ws, const float* W1c, int ld_w1c, int n_letters,
+                       float* dWs, float* dW1c, void* stream);
+
 /* Weight / bias gradient of an nn.Linear over per-residue rows (autograd of the node-level linears, :78-93, :151-155):
  * dW[o][i] += sum_n dY[n][o] X[n][i]  (row strides ldy, ldx, ldw), dbias[o] += sum_n dY[n][o].  Products as three
  * f16-split MFMA terms with fp32 accumulation (relative error per product <= ~2^-21); each 32-row batch of dY is scaled

@@ -516,6 +516,81 @@ extern "C" int mpnn_pack_blocks(const float* const* blocks, const int* ld, const
   MPNN_LAUNCH_CHECK();
 }
 
+// ---------------------------------------------------------------------------
+// Sequence term of a decoder layer in training (reference :478-483: h_S = W_s(S) enters the third column block of
+// the layer's W1): with TS = W_s W1c^T a table of n_letters rows, the term of residue n is TS[S[n]].  Three tiny
+// kernels in plain fp32 FMAs, each sum in a fixed order (the operands are gradient-sized: no f16 splitting, no
+// scaling):   TS[l][o] = sum_i W_s[l][i] W1c[o][i];   A[n] = A0[n] + TS[S[n]];
+//             dW_s[l][i] = sum_o dTS[l][o] W1c[o][i],  dW1c[o][i] = sum_l dTS[l][o] W_s[l][i]
+// (dTS arrives as mpnn_node_wgrad wrote it from one-hot rows: [feature o][letter l], row stride ld_dts).
+// ---------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(MPNN_H)
+k_seq_table(const float* __restrict__ Ws, const float* __restrict__ W1c, int ld, float* __restrict__ TS) {
+  __shared__ float ws[MPNN_H];
+  const int l = blockIdx.x, o = threadIdx.x;
+  ws[o] = Ws[(size_t)l * MPNN_H + o];
+  __syncthreads();
+  const float* w = W1c + (size_t)o * ld;
+  float acc = 0.f;
+  for (int i = 0; i < MPNN_H; ++i) acc = fmaf(ws[i], w[i], acc);
+  TS[(size_t)l * MPNN_H + o] = acc;
+}
+
+__global__ void __launch_bounds__(256)
+k_add_table_rows(const f32x4* __restrict__ A0, const f32x4* __restrict__ TS, const long long* __restrict__ S, int n_letters,
+                 long long n4, f32x4* __restrict__ A) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;  // (row, quad of features)
+  if (idx >= n4) return;
+  const long long row = idx >> 5;
+  const long long s = S[row];
+  f32x4 v = A0[idx];
+  if (s >= 0 && s < n_letters) v += TS[s * (MPNN_H / 4) + (idx & 31)];
+  A[idx] = v;
+}
+
+__global__ void __launch_bounds__(MPNN_H)
+k_seq_table_bwd(const float* __restrict__ dTSt, int ld_dts, const float* __restrict__ Ws, const float* __restrict__ W1c,
+                int ld, int n_letters, float* __restrict__ dWs, float* __restrict__ dW1c) {
+  const int i = threadIdx.x;
+  if ((int)blockIdx.x < n_letters) {  // dW_s row l
+    const int l = blockIdx.x;
+    float acc = 0.f;
+    for (int o = 0; o < MPNN_H; ++o) acc = fmaf(dTSt[(size_t)o * ld_dts + l], W1c[(size_t)o * ld + i], acc);
+    dWs[(size_t)l * MPNN_H + i] = acc;
+  } else {                            // dW1c row o
+    const int o = blockIdx.x - n_letters;
+    float acc = 0.f;
+    for (int l = 0; l < n_letters; ++l) acc = fmaf(dTSt[(size_t)o * ld_dts + l], Ws[(size_t)l * MPNN_H + i], acc);
+    dW1c[(size_t)o * MPNN_H + i] = acc;
+  }
+}
+}  // namespace
+
+extern "C" int mpnn_seq_table(const float* Ws, const float* W1c, int ld_w1c, int n_letters, float* TS, void* stream) {
+  MPNN_CHECK_ARG(Ws && W1c && TS && n_letters > 0 && ld_w1c >= MPNN_H, "mpnn_seq_table: bad arguments");
+  hipLaunchKernelGGL(k_seq_table, dim3(n_letters), dim3(MPNN_H), 0, (hipStream_t)stream, Ws, W1c, ld_w1c, TS);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_add_table_rows(const float* A0, const float* TS, const int64_t* S, int n_letters, int n_rows,
+                                   float* A, void* stream) {
+  MPNN_CHECK_ARG(A0 && TS && S && A && n_letters > 0 && n_rows > 0, "mpnn_add_table_rows: bad arguments");
+  const long long n4 = (long long)n_rows * (MPNN_H / 4);
+  hipLaunchKernelGGL(k_add_table_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const f32x4*)A0, (const f32x4*)TS, (const long long*)S, n_letters, n4, (f32x4*)A);
+  MPNN_LAUNCH_CHECK();
+}
+
+extern "C" int mpnn_seq_table_bwd(const float* dTS_t, int ld_dts, const float* Ws, const float* W1c, int ld_w1c,
+                                  int n_letters, float* dWs, float* dW1c, void* stream) {
+  MPNN_CHECK_ARG(dTS_t && Ws && W1c && dWs && dW1c && n_letters > 0 && ld_dts >= n_letters && ld_w1c >= MPNN_H,
+                 "mpnn_seq_table_bwd: bad arguments");
+  hipLaunchKernelGGL(k_seq_table_bwd, dim3(n_letters + MPNN_H), dim3(MPNN_H), 0, (hipStream_t)stream, dTS_t, ld_dts, Ws,
+                     W1c, ld_w1c, n_letters, dWs, dW1c);
+  MPNN_LAUNCH_CHECK();
+}
+
 static DropCfg make_drop(float p, uint32_t seed) {
   DropCfg d;
   d.thresh = p > 0.f ? (unsigned)((double)p * 4294967296.0) : 0u;

@@ -115,9 +115,14 @@ class Graph:
         return self.N * 8 * self.KT * 256
 
 
-def _pack_blocks(blocks):
-    """blocks: list of (view [128,128] with unit inner stride, transposed?) -> list of packed [16384] tensors
-    (f16 hi/lo A fragments), all produced by one launch per 16 blocks (mpnn_pack_blocks)."""
+def _pack_flat(blocks):
+    """blocks: list of (view [128,128] with unit inner stride, transposed?) -> their packed forms (f16 hi/lo A
+    fragments, 16384 floats each) back to back in one tensor, by one launch (mpnn_pack_blocks).
+    Packing right before the kernel that reads the blocks is deliberate: one up-front launch per step for all ~190
+    blocks (38 launches -> 1) was built and measured 0.4-0.6 ms per step SLOWER at 20 x 512 (10.87 -> 11.3 ms on one
+    box, three repetitions; 11.65 with a persistent buffer) although it removes GPU work and host time - a block packed
+    microseconds before its reader is still in the caches when all 256 workgroups ask for it at once, one packed
+    milliseconds earlier has been flushed by the 250 MB edge tensors in between."""
     import ctypes
     n = len(blocks)
     views = [b[0].detach() for b in blocks]
@@ -128,7 +133,13 @@ def _pack_blocks(blocks):
     lds = (ctypes.c_int * n)(*[v.stride(0) for v in views])
     trs = (ctypes.c_int * n)(*[1 if b[1] else 0 for b in blocks])
     call("mpnn_pack_blocks", ptrs, lds, trs, n, ptr(out), stream_ptr())
-    return [out[i * 16384:(i + 1) * 16384] for i in range(n)]
+    return out
+
+
+def _pack_blocks(blocks):
+    """_pack_flat as a list of [16384] tensors, one per block."""
+    out = _pack_flat(blocks)
+    return [out[i * 16384:(i + 1) * 16384] for i in range(len(blocks))]
 
 
 # mpnn_message_bwd_fused (K <= 48) instead of mpnn_message_bwd + 2 x mpnn_edge_wgrad
@@ -287,6 +298,47 @@ class TableRowsFn(torch.autograd.Function):
         call("mpnn_node_wgrad", ptr(d_rows), H, H, ptr(onehot), onehot.shape[1], ctx.n_rows, d_rows.shape[0], ptr(dWt),
              onehot.shape[1], None, ptr(ws), ws.numel(), stream_ptr())
         return dWt[:, :ctx.n_rows].t().contiguous(), None, None
+
+
+class SeqTermFn(torch.autograd.Function):
+    """A[n] = A0[n] + (W_s W1c^T)[S[n]]: the decoder's sequence term (reference :478-483, h_S = W_s(S) entering the
+    third column block of W1) added to the rows the decoded neighbours gather.  Forward: the n_letters-row table
+    (mpnn_seq_table) and one add-gather (mpnn_add_table_rows).  Backward: the table's gradient as a node-level weight
+    gradient against one-hot rows of S (mpnn_node_wgrad: a fixed summation order), then dW_s and dW1c from it in one
+    small launch (mpnn_seq_table_bwd).  All plain fp32: gradient-sized operands need no scaling here.  (Round 2 built
+    this from LinearFn + TableRowsFn: ~20 small launches per layer and backward pass.)"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, A0, Ws, W1c, S, onehot):
+        assert W1c.shape == (H, H) and W1c.stride(1) == 1 and Ws.shape[1] == H
+        A0 = A0.contiguous()
+        Wsc = Ws.detach().float().contiguous()
+        n_letters = Wsc.shape[0]
+        TS = torch.empty(n_letters, H, device=A0.device, dtype=torch.float32)
+        st = stream_ptr()
+        call("mpnn_seq_table", ptr(Wsc), W1c.data_ptr(), W1c.stride(0), n_letters, ptr(TS), st)
+        A = torch.empty_like(A0)
+        call("mpnn_add_table_rows", ptr(A0), ptr(TS), ptr(S), n_letters, A0.shape[0], ptr(A), st)
+        ctx.save_for_backward(Wsc, W1c, onehot)
+        return A
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, dA):
+        Wsc, W1c, onehot = ctx.saved_tensors
+        dA = dA.contiguous()
+        dev = dA.device
+        n_letters = Wsc.shape[0]
+        dTSt = _zeros(dev, H, onehot.shape[1])      # [feature][letter]
+        ws = _workspace(dev)
+        call("mpnn_node_wgrad", ptr(dA), H, H, ptr(onehot), onehot.shape[1], n_letters, dA.shape[0], ptr(dTSt),
+             onehot.shape[1], None, ptr(ws), ws.numel(), stream_ptr())
+        dWs = torch.empty(n_letters, H, device=dev, dtype=torch.float32)
+        dW1c = torch.empty(H, H, device=dev, dtype=torch.float32)
+        call("mpnn_seq_table_bwd", ptr(dTSt), onehot.shape[1], ptr(Wsc), W1c.data_ptr(), W1c.stride(0), n_letters,
+             ptr(dWs), ptr(dW1c), stream_ptr())
+        return dA, dWs, dW1c, None, None
 
 
 class GradSlot:
@@ -563,19 +615,17 @@ class NodeUpdateFn(torch.autograd.Function):
         nproj = len(projs) // 2
         scale, p_drop, seed = meta
         hV_in, gsum = hV_in.contiguous(), gsum.contiguous()
-        pk = _pack_blocks([(W3, False)] + [(Win[H * q:H * (q + 1)], False) for q in range(4)] +
+        base = _pack_flat([(W3, False)] + [(Win[H * q:H * (q + 1)], False) for q in range(4)] +
                           [(Wout[:, H * q:H * (q + 1)], False) for q in range(4)] +
                           [(projs[2 * p], False) for p in range(nproj)])
-        base = pk[0]._base if pk[0]._base is not None else pk[0]  # consecutive blocks of one buffer
-        w3p, winp, woutp = pk[0], base[16384:5 * 16384], base[5 * 16384:9 * 16384]
+        w3p, winp, woutp = base[:16384], base[16384:5 * 16384], base[5 * 16384:9 * 16384]
         vec = [v.detach().contiguous() for v in (b3, ln1w, ln1b, bin_, bout, ln2w, ln2b)]
         wprojp = bproj = PQ = None
         if nproj:
             wprojp = base[9 * 16384:]
-            bproj = torch.zeros(nproj * H, device=dev, dtype=torch.float32)
-            for p in range(nproj):
-                if projs[2 * p + 1] is not None:
-                    bproj[p * H:(p + 1) * H] = projs[2 * p + 1].detach()
+            zero_h = _zeros(dev, H)
+            bproj = torch.cat([projs[2 * p + 1].detach().float() if projs[2 * p + 1] is not None else zero_h
+                               for p in range(nproj)])  # one launch (a fill and a copy per bias otherwise)
             PQ = torch.empty(nproj, N, H, device=dev, dtype=torch.float32)
         hV_out = torch.empty(N, H, device=dev, dtype=torch.float32)
         x1pre, x2pre = torch.empty_like(hV_out), torch.empty_like(hV_out)
@@ -603,9 +653,8 @@ class NodeUpdateFn(torch.autograd.Function):
         dPQb = wprojT = None
         if nproj:
             dPQb = torch.stack([d if d is not None else torch.zeros(N, H, device=dev) for d in dPQ])
-        pk = _pack_blocks([(W, True) for W in Wp] + [(Wout[:, H * q:H * (q + 1)], True) for q in range(4)] +
+        base = _pack_flat([(W, True) for W in Wp] + [(Wout[:, H * q:H * (q + 1)], True) for q in range(4)] +
                           [(Win[H * q:H * (q + 1)], True) for q in range(4)] + [(W3, True)])
-        base = pk[0]._base if pk[0]._base is not None else pk[0]
         o = nproj * 16384
         wprojT = base[:o] if nproj else None
         woutT, winT, w3T = base[o:o + 4 * 16384], base[o + 4 * 16384:o + 8 * 16384], base[o + 8 * 16384:o + 9 * 16384]
@@ -651,10 +700,10 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
     N = B * L
     S = engine._i64(S)
     residue_idx, chain_labels = engine._i64(residue_idx), engine._i64(chain_encoding_all)
+    _ZEROS.reset(dev)  # gradient accumulators of this step's backward pass
     fm = model.features
     training = model.training
     p_drop = float(model.dropout_p) if training else 0.0
-    _ZEROS.reset(dev)  # gradient accumulators of this step's backward pass
     engine.invalidate_packed(model)  # an optimizer step follows: the inference kernels' packed weights go stale
     with torch.no_grad():
         atoms, _, E_idx64, E_idx32, _, edge_mask, K = engine._geometry(fm, X, mask, fix_backbone_noise, training)
@@ -721,7 +770,7 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
         Pa, A0, Benc = proj[0], proj[1], proj[2:]
         for l, lyr in enumerate(dec):
             W1 = W1s[id(lyr)]
-            A = A0 + TableRowsFn.apply(linear(model.W_s.weight, W1[2]), Sflat, onehot)
+            A = SeqTermFn.apply(A0, model.W_s.weight, W1[2], Sflat, onehot)
             gsum, cnt = MessageFn.apply(g, slot, True, hE, Pa, A, Benc[l], W1[1], lyr.W2.weight, lyr.W2.bias)
             nxt = [(W1s[id(dec[l + 1])][0], dec[l + 1].W1.bias), (W1s[id(dec[l + 1])][3], None)] \
                 if l + 1 < len(dec) else []

@@ -674,3 +674,31 @@ def test_fused_edge_update_backward_scale_bound_holds_for_extreme_layernorms():
         a, w = out[True][k].double(), out[False][k].double()
         assert bool(torch.isfinite(a).all()), k
         assert float((a - w).norm()) <= 1e-4 * float(w.norm()) + 1e-12, (k, float((a - w).norm()), float(w.norm()))
+
+
+@pytest.mark.parametrize("n_letters,N", [(21, 777), (32, 64)])
+def test_sequence_term_kernels_vs_aten(n_letters, N):
+    """SeqTermFn (mpnn_seq_table / mpnn_add_table_rows / mpnn_seq_table_bwd; reference :478-483, h_S = W_s(S) entering the
+    third column block of the decoder's W1): A = A0 + (W_s W1c^T)[S] and the gradients of A0, W_s and W1c against fp64
+    ATen autograd.  W1c is a strided column block of a [128, 512] weight, as in the model."""
+    from mpnn_amd import training as T
+
+    gen = torch.Generator().manual_seed(5)
+    W1 = (torch.randn(128, 512, generator=gen) * 0.1).cuda().requires_grad_(True)
+    Ws = torch.randn(n_letters, 128, generator=gen).cuda().requires_grad_(True)
+    A0 = torch.randn(N, 128, generator=gen).cuda().requires_grad_(True)
+    S = torch.randint(0, n_letters, (N,), generator=gen).cuda()
+    dA = (torch.randn(N, 128, generator=gen) * 1e-4).cuda()      # gradient-sized
+    onehot = torch.nn.functional.one_hot(S, 32 * ((n_letters + 31) // 32)).float()
+    T._ZEROS.reset(torch.device("cuda", 0))
+    A = T.SeqTermFn.apply(A0, Ws, W1.split(128, dim=1)[2], S, onehot)
+    A.backward(dA)
+    got = [A.detach().double().cpu(), A0.grad.double().cpu(), Ws.grad.double().cpu(), W1.grad.double().cpu()]
+    W1d, Wsd, A0d = [t.detach().double().cpu().requires_grad_(True) for t in (W1, Ws, A0)]
+    Ad = A0d + (Wsd @ W1d[:, 256:384].t())[S.cpu()]
+    Ad.backward(dA.double().cpu())
+    want = [Ad.detach(), A0d.grad, Wsd.grad, W1d.grad]
+    for name, g_, w_ in zip(("A", "dA0", "dW_s", "dW1"), got, want):
+        err = (g_ - w_).norm() / max(w_.norm().item(), 1e-30)
+        assert err < 2e-6, f"{name}: relative error {err:.2e}"
+    assert torch.equal(W1.grad[:, :256], torch.zeros_like(W1.grad[:, :256]))   # only the third column block moves
