@@ -402,6 +402,19 @@ int mpnn_feature_chunks(const float* atoms, const int32_t* E_idx32, const int64_
                         const int64_t* chain_labels, const float* rbf_mu, int B, int L, int K, int n_atoms,
                         float* chunks_frag, void* stream);
 
+/* The weight gradient those chunks exist for, without materialising them (training backward of edge_embedding,
+ * model_utils.py:334-358): dF[c][o][i] += sum over residues and edges of dE0[.., o] * F_c[.., i], c = 0 .. nch - 1
+ * (nch = ceil((n_atoms^2 + 5) / 8) chunks of 128 raw features: the 16 RBFs of each atom pair, then the one-hot of the
+ * 66 relative-position buckets, zero beyond), each chunk's values computed inside the contraction kernel from atoms,
+ * neighbour ids, residue numbers and chain labels exactly as mpnn_edge_features_train computes them.  dE0_frag: the
+ * gradient of the pre-LayerNorm embedding in the fragment layout, dE0_absmax its largest magnitude (device scalar, as
+ * mpnn_edge_features_bwd leaves it).  dF [nch][128][128] accumulates: zero it first.  dbias [128] (may be NULL)
+ * accumulates the column sums of dE0 (the edge-list variant's embedding bias).  Deterministic (ordered partials);
+ * workspace as for mpnn_edge_wgrad. */
+int mpnn_feature_wgrad(const float* dE0_frag, const float* dE0_absmax, const float* atoms, const int32_t* E_idx32,
+                       const int64_t* residue_idx, const int64_t* chain_labels, const float* rbf_mu, int B, int L, int K,
+                       int n_atoms, float* dF, float* dbias, float* workspace, int workspace_floats, void* stream);
+
 /* Training forward of mpnn_node_update (:81-88, :127-137, :151-155): also stores x1pre = h + drop(dh), the FFN
  * pre-activation a [n_nodes,512] and x2pre = x1 + drop(FFN) for the backward kernel; applies the layers' two node-level
  * dropouts (counter-based, ids node*128+feature; the second with seed ^ 0x5bd1e995) when p_drop > 0; writes the

@@ -84,6 +84,7 @@ SIGNATURES = {
                             [_F, ctypes.c_uint32, _P, _I, _P],
     "mpnn_node_wgrad_batch": [_I] + [_P] * 9 + [_I, _P, _I, _P],
     "mpnn_pack_blocks": [_P, _P, _P, _I, _P, _P],
+    "mpnn_feature_wgrad": [_P] * 7 + [_I] * 4 + [_P, _P, _P, _I, _P],
     "mpnn_seq_table": [_P, _P, _I, _I, _P, _P],
     "mpnn_add_table_rows": [_P, _P, _P, _I, _I, _P, _P],
     "mpnn_seq_table_bwd": [_P, _I, _P, _P, _I, _I, _P, _P, _P],

@@ -372,10 +372,25 @@ __device__ __forceinline__ void split4(const f32x4 x, h4& hi, h4& lo) {
 #ifndef MPNN_WGRAD_WG_PER_CU
 #define MPNN_WGRAD_WG_PER_CU (MPNN_WGRAD_WAVES == 8 ? 2 : 3)
 #endif
-template <bool A_NAT, bool B_GELU, int KTM>
+// FEAT = 5 / 6 (atoms per residue): the B operand is not read but COMPUTED - chunk `fa.chunk` (128 features = 8 tiles)
+// of the featurizer's raw inputs, tile T = 8 chunk + wave: the 16 RBFs of atom pair T (T < FEAT^2), the one-hot of the
+// relative-position bucket (the next five tiles), zero beyond (reference :334-356, :170-176).  Round 2 wrote these
+// chunks to memory first (mpnn_feature_chunks: 1 GB per step) and read them back here.  The neighbour ids are loaded
+// two residues ahead and the neighbours' atoms one ahead, so neither wait is exposed.
+struct FeatArgs {
+  const float* atoms;           // [N][6][4]
+  const int* E_idx;             // [N][Kp] row-local neighbour ids
+  const long long* residue_idx; // [N]
+  const long long* chain;       // [N]
+  const float* rbf_mu;          // [16]
+  int L, chunk;
+};
+
+template <bool A_NAT, bool B_GELU, int KTM, int FEAT = 0>
 __global__ void __launch_bounds__(64 * MPNN_WGRAD_WAVES)
 k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigned* __restrict__ amax, int N, int KT,
-        float* __restrict__ part) {
+        float* __restrict__ part, FeatArgs fa) {
+  static_assert(FEAT == 0 || MPNN_WGRAD_WAVES == 8, "the feature form gives each wave one tile");
   constexpr int WG_LDK = 16 * KTM + 4;
   __shared__ _Float16 sA[2][MPNN_H][WG_LDK];
   __shared__ _Float16 sB[2][MPNN_H][WG_LDK];
@@ -395,6 +410,54 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
   const float sc = pow2_scale_from_bits(*amax), un = pow2_inverse(sc);  // see grad_to_bfrag
   // this thread's share of a residue: feature tiles t = TT wave + {0 .. TT-1}, every column tile
   f32x4 va[TT][KTM], vb[TT][KTM];
+  // feature form: this wave's tile, the neighbour ids of the residue whose operands are fetched next, and the raw
+  // values its B tile is computed from (neighbour atom of the pair / neighbour's residue number and chain)
+  const int T = FEAT ? 8 * fa.chunk + wave : 0;
+  constexpr int NPAIR = FEAT * FEAT;
+  int jn[KTM];
+  f32x4 own = f32x4{0.f, 0.f, 0.f, 0.f};
+  long long ri = 0, ci = 0;
+  float muc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (FEAT) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) muc[r] = fa.rbf_mu[4 * g + r] * 0.96089792702915982f;
+  }
+  auto load_ids = [&](int node) {
+#pragma unroll
+    for (int c = 0; c < KTM; ++c)
+      if (c < KT) jn[c] = (node / fa.L) * fa.L + fa.E_idx[(size_t)node * Kp + 16 * c + col];
+  };
+  auto feature_raw = [&](int node, int c) {  // -> vb[0][c]: xyz of the pair's neighbour atom | (residue number, chain)
+    if (T < NPAIR) {
+      vb[0][c] = reinterpret_cast<const f32x4*>(fa.atoms + (size_t)jn[c] * 24)[T % (FEAT ? FEAT : 1)];
+    } else if (T < NPAIR + 5) {
+      const long long rj = fa.residue_idx[jn[c]], cj = fa.chain[jn[c]];
+      vb[0][c] = f32x4{__int_as_float((int)rj), __int_as_float((int)(rj >> 32)), __int_as_float((int)cj),
+                       __int_as_float((int)(cj >> 32))};
+    }
+  };
+  auto feature_value = [&](f32x4 raw) -> f32x4 {
+    f32x4 x = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (T < NPAIR) {
+      const float dx = own.x - raw.x, dy = own.y - raw.y, dz = own.z - raw.z;
+      const float dist = __builtin_amdgcn_sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-6f);  // as the forward kernel's
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float z = fmaf(dist, 0.96089792702915982f, -muc[r]);
+        x[r] = __builtin_amdgcn_exp2f(-(z * z));
+      }
+    } else if (T < NPAIR + 5) {
+      const long long rj = ((long long)(unsigned)__float_as_int(raw.x)) | ((long long)__float_as_int(raw.y) << 32);
+      const long long cj = ((long long)(unsigned)__float_as_int(raw.z)) | ((long long)__float_as_int(raw.w) << 32);
+      long long d = ri - rj + 32;
+      d = d < 0 ? 0 : (d > 64 ? 64 : d);
+      if (ci != cj) d = 65;
+      const int f0 = 16 * (T - NPAIR) + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[r] = (f0 + r == (int)d) ? 1.0f : 0.0f;
+    }
+    return x;
+  };
   auto fetch_one = [&](int node, int tt, int c) {
     const int t = TT * wave + tt;
     if (A_NAT)
@@ -402,7 +465,10 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
           reinterpret_cast<const f32x4*>(A + ((size_t)node * Kp + 16 * c + col) * MPNN_H + 16 * t + 4 * g));
     else
       va[tt][c] = WGRAD_LOAD(&Af[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane]);
-    vb[tt][c] = WGRAD_LOAD(&Bf[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane]);
+    if (FEAT)
+      feature_raw(node, c);
+    else
+      vb[tt][c] = WGRAD_LOAD(&Bf[((size_t)node * MPNN_NT + t) * KT * 64 + c * 64 + lane]);
   };
   auto fetch = [&](int node) {
 #pragma unroll
@@ -413,8 +479,20 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
   };
   int node = blockIdx.x;
   const int Nend = N, nstep = gridDim.x;
-  if (node < Nend) fetch(node);
+  // the residue the staging loop works on owns `own_cur` / ri / ci; the values fetched for the next one wait in *_nx
+  f32x4 own_nx = own;
+  long long ri_nx = 0, ci_nx = 0;
+  auto fetch_own = [&](int nd) {
+    if (T < NPAIR) own_nx = reinterpret_cast<const f32x4*>(fa.atoms + (size_t)nd * 24)[T / (FEAT ? FEAT : 1)];
+    else if (T < NPAIR + 5) { ri_nx = fa.residue_idx[nd]; ci_nx = fa.chain[nd]; }
+  };
+  if (node < Nend) {
+    if (FEAT) { load_ids(node); fetch_own(node); }
+    fetch(node);
+    if (FEAT && node + nstep < Nend) load_ids(node + nstep);  // ids one residue further than the operands
+  }
   for (; node < Nend; node += nstep) {
+    if (FEAT) { own = own_nx; ri = ri_nx; ci = ci_nx; }
 #ifdef MPNN_ABL_WGRAD_STREAM  // timing-only ablation build (never shipped): the operand streams alone
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt)
@@ -431,7 +509,7 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
 #pragma unroll
       for (int c = 0; c < KTM; ++c) {
         if (c < KT) {
-          f32x4 a = va[tt][c], b = vb[tt][c];
+          f32x4 a = va[tt][c], b = FEAT ? feature_value(vb[tt][c]) : vb[tt][c];
           if (B_GELU) b = gelu4(b);
           bacc[tt] += a;
           a *= sc;
@@ -451,7 +529,11 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
       }
     }
     __syncthreads();
-    if (node + nstep < Nend) fetch(node + nstep);  // next residue's loads fly under the MFMAs
+    if (node + nstep < Nend) {  // next residue's loads fly under the MFMAs
+      if (FEAT) fetch_own(node + nstep);
+      fetch(node + nstep);      // (feature form: with the ids loaded one iteration ago)
+      if (FEAT && node + 2 * nstep < Nend) load_ids(node + 2 * nstep);
+    }
     for (int c = 0; c < KT; ++c) {
       h4 ah[TT], al[TT];
 #pragma unroll
@@ -1471,8 +1553,8 @@ extern "C" int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax
   const unsigned* am = (const unsigned*)A_absmax;
 #define MPNN_WGRAD_LAUNCH(AN, BG)                                                                              \
   do {                                                                                                         \
-    if (KT <= 3) hipLaunchKernelGGL((k_wgrad<AN, BG, 3>), grid, block, 0, st, A, Bf, am, n_nodes, KT, workspace); \
-    else hipLaunchKernelGGL((k_wgrad<AN, BG, 4>), grid, block, 0, st, A, Bf, am, n_nodes, KT, workspace);        \
+    if (KT <= 3) hipLaunchKernelGGL((k_wgrad<AN, BG, 3>), grid, block, 0, st, A, Bf, am, n_nodes, KT, workspace, FeatArgs{}); \
+    else hipLaunchKernelGGL((k_wgrad<AN, BG, 4>), grid, block, 0, st, A, Bf, am, n_nodes, KT, workspace, FeatArgs{});        \
   } while (0)
   if (a_rows) {
     if (b_gelu) MPNN_WGRAD_LAUNCH(true, true); else MPNN_WGRAD_LAUNCH(true, false);
@@ -1482,6 +1564,45 @@ extern "C" int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax
 #undef MPNN_WGRAD_LAUNCH
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((WG_PART + 15) / 16), dim3(256), 0, st, workspace, nwg, (size_t)WG_PART, dW,
                      dbias);
+  MPNN_LAUNCH_CHECK();
+}
+
+// Weight gradient of the featurizer's edge embedding: dF[c][o][i] += sum_{node, e} dE0[node, e, o] F_c[node, e, i] for
+// the chunks c of the raw feature vector (RBFs of the atom pairs, then the one-hot position bucket), the chunk's values
+// computed inside the contraction kernel (k_wgrad, FEAT form) instead of read from memory.
+extern "C" int mpnn_feature_wgrad(const float* dE0_frag, const float* dE0_absmax, const float* atoms,
+                                  const int32_t* E_idx32, const int64_t* residue_idx, const int64_t* chain_labels,
+                                  const float* rbf_mu, int B, int L, int K, int n_atoms, float* dF, float* dbias,
+                                  float* workspace, int workspace_floats, void* stream) {
+  MPNN_CHECK_ARG(dE0_frag && dE0_absmax && atoms && E_idx32 && residue_idx && chain_labels && rbf_mu && dF && workspace,
+                 "mpnn_feature_wgrad: null pointer");
+  MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && (n_atoms == 5 || n_atoms == 6), "mpnn_feature_wgrad: bad sizes");
+  const int KT = (K + 15) / 16, n_nodes = B * L;
+  const int nch = (n_atoms * n_atoms + 5 + 7) / 8;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  const int per_cu = KT <= 3 ? MPNN_WGRAD_WG_PER_CU : (MPNN_WGRAD_WAVES == 8 ? 2 : 1);
+  int nwg = n_nodes < per_cu * cus ? n_nodes : per_cu * cus;
+  if (nwg > workspace_floats / WG_PART) nwg = workspace_floats / WG_PART;
+  MPNN_CHECK_ARG(nwg >= 1, "mpnn_feature_wgrad: workspace holds no partial (mpnn_workspace_bytes(\"mpnn_edge_wgrad\"))");
+  dim3 grid(nwg), block(64 * MPNN_WGRAD_WAVES);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned* am = (const unsigned*)dE0_absmax;
+  FeatArgs fa{atoms, E_idx32, (const long long*)residue_idx, (const long long*)chain_labels, rbf_mu, L, 0};
+  for (int c = 0; c < nch; ++c) {  // the launches share the workspace: each chunk's partials are reduced before the next
+    fa.chunk = c;
+#define MPNN_FEAT_LAUNCH(KTM, AA)                                                                                \
+    hipLaunchKernelGGL((k_wgrad<false, false, KTM, AA>), grid, block, 0, st, dE0_frag, (const f32x4*)nullptr, am, \
+                       n_nodes, KT, workspace, fa)
+    if (n_atoms == 5) { if (KT <= 3) MPNN_FEAT_LAUNCH(3, 5); else MPNN_FEAT_LAUNCH(4, 5); }
+    else              { if (KT <= 3) MPNN_FEAT_LAUNCH(3, 6); else MPNN_FEAT_LAUNCH(4, 6); }
+#undef MPNN_FEAT_LAUNCH
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((WG_PART + 15) / 16), dim3(256), 0, st, workspace, nwg, (size_t)WG_PART,
+                       dF + (size_t)c * MPNN_H * MPNN_H, c == 0 ? dbias : nullptr);
+  }
   MPNN_LAUNCH_CHECK();
 }
 

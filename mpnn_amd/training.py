@@ -9,7 +9,7 @@ What runs where (round 1):
     `.grad`s on the reference-shaped parameters;
   * neighbour search, backbone atoms, decoding-order ranks: the forward HIP kernels (no gradient flows there);
   * the edge featurizer (RBF / positional embedding -> edge_embedding -> norm_edges -> W_e): forward and backward on
-    HIP kernels too (mpnn_edge_features_train / mpnn_edge_features_bwd / mpnn_feature_chunks + mpnn_edge_wgrad);
+    HIP kernels too (mpnn_edge_features_train / mpnn_edge_features_bwd / mpnn_feature_wgrad + mpnn_edge_wgrad);
   * per-node work (W3, LayerNorms, FFN, the next kernels' projections): mpnn_node_update_train / mpnn_node_update_bwd,
     weight gradients on mpnn_node_wgrad; only the occupancy MLP, the sequence-embedding term, the 21-letter head and
     the loss are ATen ops under autograd.
@@ -560,14 +560,13 @@ class FeaturesFn(torch.autograd.Function):
         dWe, dbe = _wgrad(dhE, False, amax[0:1], E, False, g, True)
         nrbf = na * na * 16
         nch = (na * na + 5 + 7) // 8
-        chunks = torch.empty(nch * g.frag_numel(), device=dev, dtype=torch.float32)
-        call("mpnn_feature_chunks", ptr(atoms), ptr(g.E_idx32), ptr(residue_idx), ptr(chain_labels), ptr(mu), g.B, g.L,
-             g.K, na, ptr(chunks), st)
-        n = g.frag_numel()
-        parts = [_wgrad(dE0, False, amax[1:2], chunks[c * n:(c + 1) * n], False, g, ctx.has_bemb and c == 0)
-                 for c in range(nch)]
-        dF = torch.cat([p_[0] for p_ in parts], dim=1)                      # [128, nch*128]: d / d(raw feature)
-        dbemb = parts[0][1]                                                 # column sums of dE0 (None without the bias)
+        # d / d(raw feature) [128, nch*128]: dE0 contracted with the raw features (RBFs, position one-hot), which the
+        # kernel recomputes per residue instead of reading 1 GB of materialised chunks (mpnn_feature_chunks, round 2)
+        dFc = _zeros(dev, nch, H, H)
+        dbemb = _zeros(dev, H) if ctx.has_bemb else None                    # column sums of dE0 (None without the bias)
+        call("mpnn_feature_wgrad", ptr(dE0), ptr(amax[1:2]), ptr(atoms), ptr(g.E_idx32), ptr(residue_idx),
+             ptr(chain_labels), ptr(mu), g.B, g.L, g.K, na, ptr(dFc), ptr(dbemb), ptr(ws), ws.numel(), st)
+        dF = dFc.permute(1, 0, 2).reshape(H, nch * H)
         G = dF[:, nrbf:nrbf + 66]                                           # sum of dE0 rows per position bucket
         W = Wemb.detach()
         npos = W.shape[1] - nrbf

@@ -702,3 +702,50 @@ def test_sequence_term_kernels_vs_aten(n_letters, N):
         err = (g_ - w_).norm() / max(w_.norm().item(), 1e-30)
         assert err < 2e-6, f"{name}: relative error {err:.2e}"
     assert torch.equal(W1.grad[:, :256], torch.zeros_like(W1.grad[:, :256]))   # only the third column block moves
+
+
+@pytest.mark.parametrize("kw,L", [(dict(k_neighbors=48), 96), (dict(k_neighbors=30, use_virtual_center=True), 64),
+                                  (dict(k_neighbors=64), 80)])
+def test_feature_wgrad_recomputes_the_chunks(kw, L):
+    """mpnn_feature_wgrad (the featurizer's weight gradient with the raw features computed inside the contraction) against
+    the materialised form it replaces: mpnn_feature_chunks followed by one mpnn_edge_wgrad per chunk.  Same feature
+    arithmetic, same contraction kernel, same order of partial sums: equal to rounding (the chunk kernel is compiled
+    without FMA contraction, as the whole featurizer source is for the neighbour search; the squared distances differ in
+    the last bit)."""
+    import mpnn_amd
+    from mpnn_amd import engine, training as T
+    from mpnn_amd._lib import call, ptr, stream_ptr
+    from mpnn_amd.synthetic import synthetic_batch
+
+    dev = torch.device("cuda", 0)
+    model = mpnn_amd.ProteinMPNN(augment_eps=0.0, dropout=0.0, **kw).to(dev)
+    b = synthetic_batch(B=2, L=L, seed=9, lengths=[L, L - 7], n_chains=2)
+    X, mask = b["X"].to(dev), b["mask"].to(dev).float()
+    ridx, chain = b["residue_idx"].to(dev), b["chain_encoding_all"].to(dev)
+    with torch.no_grad():
+        atoms, _, E64, E32, _, emask, K = engine._geometry(model.features, X, mask, None, False)
+    g = T.Graph(E64, E32, mask.reshape(-1).contiguous(), emask, K)
+    na = 6 if kw.get("use_virtual_center") else 5
+    nch = (na * na + 5 + 7) // 8
+    gen = torch.Generator().manual_seed(3)
+    dE0 = (torch.randn(g.frag_numel(), generator=gen) * 1e-4).to(dev)
+    amax = dE0.abs().max().reshape(1)
+    mu = torch.linspace(2.0, 22.0, 16, device=dev)
+    T._ZEROS.reset(dev)
+    ws = T._workspace(dev)
+    st = stream_ptr()
+    dF = torch.zeros(nch, 128, 128, device=dev)
+    db = torch.zeros(128, device=dev)
+    call("mpnn_feature_wgrad", ptr(dE0), ptr(amax), ptr(atoms), ptr(g.E_idx32), ptr(ridx), ptr(chain), ptr(mu), g.B,
+         g.L, g.K, na, ptr(dF), ptr(db), ptr(ws), ws.numel(), st)
+    chunks = torch.empty(nch * g.frag_numel(), device=dev)
+    call("mpnn_feature_chunks", ptr(atoms), ptr(g.E_idx32), ptr(ridx), ptr(chain), ptr(mu), g.B, g.L, g.K, na,
+         ptr(chunks), st)
+    n = g.frag_numel()
+    for c in range(nch):
+        dW, dbc = T._wgrad(dE0, False, amax, chunks[c * n:(c + 1) * n], False, g, c == 0)
+        err = (dW - dF[c]).abs().max().item()
+        assert err <= 1e-5 * max(dW.abs().max().item(), 1e-30), f"chunk {c}: max |d| {err:.3e}"
+        if c == 0:
+            assert torch.equal(dbc, db)
+    assert dF.abs().max().item() > 0
