@@ -282,9 +282,10 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
     # profiles/r03_pmc_traffic_train.txt): in units of one residue's fragment tensor F = 8 * ceil(K/16) KiB.
     #   K <= 48 (fused backward kernels): encoder layer 25 F (message forward 3, edge-update forward 6, fused edge-update
     #   backward 6 + W11b contraction 2 + gather 1, fused message backward 6 + gather 1), decoder layer 9.67 F,
-    #   featurizer 20 F  =>  124 F for the 3 + 3 layer model;  K > 48 (unfused): 36 / 14 / 20  =>  170 F
+    #   featurizer 12 F (forward 3, backward 3, W_e contraction 2, embedding contraction 4 reads of dE0 - the raw features
+    #   are recomputed, not read)  =>  116 F for the 3 + 3 layer model;  K > 48 (unfused): 36 / 14 / 12  =>  162 F
     frag = 8 * ((K + 15) // 16) * 1024
-    step_bytes = (124 if K <= 48 else 170) * frag * B * L
+    step_bytes = (116 if K <= 48 else 162) * frag * B * L
     tbps = step_bytes / (elapsed / steps) / 1e12
     return {**(ranks or {}),
             "metric": "residues/sec (train step: fwd + bwd + AdamW) at L=512,k=48",
@@ -296,7 +297,7 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
                                    "all-reduce per step", "global_batch": B * world},
             "roofline": {"bound": "hbm", "achieved": round(tbps * 1e3, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(tbps / 8.0, 4), "bytes_per_step": step_bytes,
-                         "note": "whole step, design bytes (124 fragment tensors per residue at K <= 48: the fused "
+                         "note": "whole step, design bytes (116 fragment tensors per residue at K <= 48: the fused "
                                  "backward kernels keep da2 / dz in the workgroup and read each saved tensor once); the "
                                  "fused backward kernels themselves are LDS- / issue-bound in lock-step (2.3-3.5 TB/s), "
                                  "the forward-with-saves kernels and the weight-gradient passes run at 4-5 TB/s"},
@@ -304,7 +305,7 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
             "hip_kernels_ms_per_step": kern, "hip_kernels_total_ms": round(hip_ms, 3),
             "note": "forward, backward and weight gradients of the featurizer, edge and node stages, the output head, "
                     "the smoothed loss, the sequence-term table and the AdamW update are HIP kernels (no library GEMM on "
-                    "the path); what is left to ATen is glue: index_select of the 21-row table, one_hot(S), cat / zero "
+                    "the path); what is left to ATen is glue: one_hot(S), cat / zero "
                     "fills / copies of autograd, the decoding order's argsort; every sum is order-fixed (no "
                     "floating-point atomics): two runs give identical gradients"}
 
