@@ -573,27 +573,40 @@ k_wgrad(const float* __restrict__ A, const f32x4* __restrict__ Bf, const unsigne
 }
 
 // dW[i] += sum_w part[w][i]: 16 slices of the workgroup partials per element, met in LDS in slice order (no atomics:
-// the same bits on every run)
+// the same bits on every run).  A thread owns four consecutive elements (16-byte loads: 16 threads cover 256
+// contiguous bytes of a partial; the dword form read half-lines and took 13-15 us per launch, 17 launches a step).
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, int nparts, size_t stride,
+                                                  float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ f32x4 sl[16][17];
+  const int q = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int i4 = blockIdx.x * 16 + q;  // quad of elements
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (i4 < WG_PART / 4) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(part) + i4;
+#pragma unroll 8
+    for (int w = slice; w < nparts; w += 16) s += p[(size_t)w * (stride / 4)];
+  }
+  sl[slice][q] = s;
+  __syncthreads();
+  if (slice == 0 && i4 < WG_PART / 4) {
+    f32x4 t = sl[0][q];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sl[k][q];
+    if (i4 < MPNN_H * MPNN_H / 4) {
+      f32x4* d = reinterpret_cast<f32x4*>(dW) + i4;
+      *d = *d + t;
+    } else if (db) {
+      f32x4* d = reinterpret_cast<f32x4*>(db) + (i4 - MPNN_H * MPNN_H / 4);
+      *d = *d + t;
+    }
+  }
+}
+static_assert(WG_PART % 4 == 0 && (MPNN_H * MPNN_H) % 4 == 0, "quads must not straddle the dW / dbias boundary");
+
 __global__ void __launch_bounds__(256)
 k_wgrad_reduce(const float* __restrict__ part, int nparts, size_t stride, float* __restrict__ dW,
                float* __restrict__ db) {
-  __shared__ float sl[16][17];
-  const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
-  const int i = blockIdx.x * 16 + el;
-  float s = 0.f;
-  if (i < WG_PART)
-    for (int w = slice; w < nparts; w += 16) s += part[(size_t)w * stride + i];
-  sl[slice][el] = s;
-  __syncthreads();
-  if (slice == 0 && i < WG_PART) {
-    float t = sl[0][el];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) t += sl[k][el];
-    if (i < MPNN_H * MPNN_H)
-      dW[i] += t;
-    else if (db)
-      db[i - MPNN_H * MPNN_H] += t;
-  }
+  wgrad_reduce_body(part, nparts, stride, dW, db);
 }
 
 // ---------------------------------------------------------------------------
@@ -669,26 +682,7 @@ struct ReduceJobs {
 };
 __global__ void __launch_bounds__(256)
 k_wgrad_reduce_n(ReduceJobs jobs, int nparts, size_t stride) {
-  __shared__ float sl[16][17];
-  const float* part = jobs.part[blockIdx.y];
-  float* dW = jobs.dW[blockIdx.y];
-  float* db = jobs.db[blockIdx.y];
-  const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
-  const int i = blockIdx.x * 16 + el;
-  float s = 0.f;
-  if (i < WG_PART)
-    for (int w = slice; w < nparts; w += 16) s += part[(size_t)w * stride + i];
-  sl[slice][el] = s;
-  __syncthreads();
-  if (slice == 0 && i < WG_PART) {
-    float t = sl[0][el];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) t += sl[k][el];
-    if (i < MPNN_H * MPNN_H)
-      dW[i] += t;
-    else if (db)
-      db[i - MPNN_H * MPNN_H] += t;
-  }
+  wgrad_reduce_body(jobs.part[blockIdx.y], nparts, stride, jobs.dW[blockIdx.y], jobs.db[blockIdx.y]);
 }
 
 template <int KT, bool DEC>
@@ -1438,6 +1432,8 @@ extern "C" int mpnn_message_bwd_fused(int dec, const float* dgsum, const float* 
   int nwg = edge_grid(N, 1);
   if (nwg > (workspace_floats - 64) / (2 * WG_PART)) nwg = (workspace_floats - 64) / (2 * WG_PART);
   MPNN_CHECK_ARG(nwg >= 1, "mpnn_message_bwd_fused: workspace holds no partial (64 + 33024 floats per workgroup, one per CU)");
+  MPNN_CHECK_ARG((((uintptr_t)dW2 | (uintptr_t)db2 | (uintptr_t)dW1b | (uintptr_t)workspace) & 15) == 0,
+                 "mpnn_message_bwd_fused: dW2, db2, dW1b and workspace must be 16-byte aligned");
   unsigned* scales = reinterpret_cast<unsigned*>(workspace);
   workspace += 64;
   dim3 grid(nwg), block(FB_WAVES * 64);
@@ -1460,7 +1456,7 @@ extern "C" int mpnn_message_bwd_fused(int dec, const float* dgsum, const float* 
   }
 #undef MPNN_FB_LAUNCH
   ReduceJobs jobs = {{workspace, workspace + WG_PART, nullptr}, {dW2, dW1b, nullptr}, {db2, nullptr, nullptr}};
-  hipLaunchKernelGGL(k_wgrad_reduce_n, dim3((WG_PART + 15) / 16, 2), dim3(256), 0, st, jobs, nwg, (size_t)(2 * WG_PART));
+  hipLaunchKernelGGL(k_wgrad_reduce_n, dim3((WG_PART / 4 + 15) / 16, 2), dim3(256), 0, st, jobs, nwg, (size_t)(2 * WG_PART));
   MPNN_LAUNCH_CHECK();
 }
 
@@ -1510,6 +1506,8 @@ extern "C" int mpnn_enc_edge_update_bwd_fused(const float* dy_frag, const float*
   int nwg = edge_grid(N, 1);
   if (nwg > (workspace_floats - 64) / EU_PART) nwg = (workspace_floats - 64) / EU_PART;
   MPNN_CHECK_ARG(nwg >= 1, "mpnn_enc_edge_update_bwd_fused: workspace holds no partial (64 + 33280 floats per workgroup, one per CU)");
+  MPNN_CHECK_ARG((((uintptr_t)dW13 | (uintptr_t)db13 | (uintptr_t)dW12 | (uintptr_t)db12 | (uintptr_t)workspace) & 15) == 0,
+                 "mpnn_enc_edge_update_bwd_fused: dW13, db13, dW12, db12 and workspace must be 16-byte aligned");
   unsigned* scales = reinterpret_cast<unsigned*>(workspace);
   workspace += 64;
   hipStream_t st = (hipStream_t)stream;
@@ -1525,7 +1523,7 @@ extern "C" int mpnn_enc_edge_update_bwd_fused(const float* dy_frag, const float*
   if (KT == 1) MPNN_EU_LAUNCH(1); else if (KT == 2) MPNN_EU_LAUNCH(2); else MPNN_EU_LAUNCH(3);
 #undef MPNN_EU_LAUNCH
   ReduceJobs jobs = {{workspace, workspace + WG_PART, nullptr}, {dW13, dW12, nullptr}, {db13, db12, nullptr}};
-  hipLaunchKernelGGL(k_wgrad_reduce_n, dim3((WG_PART + 15) / 16, 2), dim3(256), 0, st, jobs, nwg, (size_t)EU_PART);
+  hipLaunchKernelGGL(k_wgrad_reduce_n, dim3((WG_PART / 4 + 15) / 16, 2), dim3(256), 0, st, jobs, nwg, (size_t)EU_PART);
   launch_partials_reduce(workspace + 2 * WG_PART, nwg, EU_PART, 2 * MPNN_H, dln, 1, st);
   MPNN_LAUNCH_CHECK();
 }
@@ -1534,6 +1532,8 @@ extern "C" int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax
                                int n_nodes, int K, float* dW, float* dbias, float* workspace, int workspace_floats,
                                void* stream) {
   MPNN_CHECK_ARG(A && A_absmax && B_frag && dW && workspace, "mpnn_edge_wgrad: null pointer");
+  MPNN_CHECK_ARG((((uintptr_t)dW | (uintptr_t)dbias | (uintptr_t)workspace) & 15) == 0,
+                 "mpnn_edge_wgrad: dW, dbias and workspace must be 16-byte aligned");
   MPNN_CHECK_ARG(n_nodes > 0 && K >= 1 && K <= 64, "mpnn_edge_wgrad: bad sizes (K <= 64)");
   const int KT = (K + 15) / 16;
   int dev = 0, cus = 256;
@@ -1562,7 +1562,7 @@ extern "C" int mpnn_edge_wgrad(const float* A, int a_rows, const float* A_absmax
     if (b_gelu) MPNN_WGRAD_LAUNCH(false, true); else MPNN_WGRAD_LAUNCH(false, false);
   }
 #undef MPNN_WGRAD_LAUNCH
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((WG_PART + 15) / 16), dim3(256), 0, st, workspace, nwg, (size_t)WG_PART, dW,
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((WG_PART / 4 + 15) / 16), dim3(256), 0, st, workspace, nwg, (size_t)WG_PART, dW,
                      dbias);
   MPNN_LAUNCH_CHECK();
 }
@@ -1577,6 +1577,8 @@ extern "C" int mpnn_feature_wgrad(const float* dE0_frag, const float* dE0_absmax
   MPNN_CHECK_ARG(dE0_frag && dE0_absmax && atoms && E_idx32 && residue_idx && chain_labels && rbf_mu && dF && workspace,
                  "mpnn_feature_wgrad: null pointer");
   MPNN_CHECK_ARG(B > 0 && L > 0 && K >= 1 && K <= 64 && (n_atoms == 5 || n_atoms == 6), "mpnn_feature_wgrad: bad sizes");
+  MPNN_CHECK_ARG((((uintptr_t)dF | (uintptr_t)dbias | (uintptr_t)workspace) & 15) == 0,
+                 "mpnn_feature_wgrad: dF, dbias and workspace must be 16-byte aligned");
   const int KT = (K + 15) / 16, n_nodes = B * L;
   const int nch = (n_atoms * n_atoms + 5 + 7) / 8;
   int dev = 0, cus = 256;
@@ -1600,7 +1602,7 @@ extern "C" int mpnn_feature_wgrad(const float* dE0_frag, const float* dE0_absmax
     if (n_atoms == 5) { if (KT <= 3) MPNN_FEAT_LAUNCH(3, 5); else MPNN_FEAT_LAUNCH(4, 5); }
     else              { if (KT <= 3) MPNN_FEAT_LAUNCH(3, 6); else MPNN_FEAT_LAUNCH(4, 6); }
 #undef MPNN_FEAT_LAUNCH
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((WG_PART + 15) / 16), dim3(256), 0, st, workspace, nwg, (size_t)WG_PART,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((WG_PART / 4 + 15) / 16), dim3(256), 0, st, workspace, nwg, (size_t)WG_PART,
                        dF + (size_t)c * MPNN_H * MPNN_H, c == 0 ? dbias : nullptr);
   }
   MPNN_LAUNCH_CHECK();

@@ -533,6 +533,7 @@ k_seq_table(const float* __restrict__ Ws, const float* __restrict__ W1c, int ld,
   __syncthreads();
   const float* w = W1c + (size_t)o * ld;
   float acc = 0.f;
+#pragma unroll 16
   for (int i = 0; i < MPNN_H; ++i) acc = fmaf(ws[i], w[i], acc);
   TS[(size_t)l * MPNN_H + o] = acc;
 }
@@ -556,11 +557,13 @@ k_seq_table_bwd(const float* __restrict__ dTSt, int ld_dts, const float* __restr
   if ((int)blockIdx.x < n_letters) {  // dW_s row l
     const int l = blockIdx.x;
     float acc = 0.f;
+#pragma unroll 16
     for (int o = 0; o < MPNN_H; ++o) acc = fmaf(dTSt[(size_t)o * ld_dts + l], W1c[(size_t)o * ld + i], acc);
     dWs[(size_t)l * MPNN_H + i] = acc;
   } else {                            // dW1c row o
     const int o = blockIdx.x - n_letters;
     float acc = 0.f;
+#pragma unroll 8
     for (int l = 0; l < n_letters; ++l) acc = fmaf(dTSt[(size_t)o * ld_dts + l], Ws[(size_t)l * MPNN_H + i], acc);
     dW1c[(size_t)o * MPNN_H + i] = acc;
   }
