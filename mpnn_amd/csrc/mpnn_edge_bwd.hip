@@ -850,7 +850,8 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
   // Operand tiles are requested about two phases ahead of their use and are NOT kept live all the way round the loop
   // (a ring one residue deep for each of the four tensors is 48 registers at every point; this is ~36):
   //   a2, dgsum, a1, masks of the next residue: top of phase 3    (used in its phases 1 / 1+2)
-  //   e:                                        top of phase 1    (used in phase 2)
+  //   e:                                        top of phase 1    (used in phase 2; requested with the others it
+  //                                             costs 14-19 spilled registers and 0.05 ms per step)
   //   dE (accumulate):                          top of phase 2    (used in phase 3)
   int node = blockIdx.x;
   if (node < N) {
@@ -1212,6 +1213,11 @@ k_edge_update_bwd_fused(const f32x4* __restrict__ dy, const f32x4* __restrict__ 
     sacc_add(2, lg);
     sacc_add(3, lb);
     FENCE();
+    if (more) {  // z / dy of the next residue (dead from here on): three phases ahead of the exchange that reads them
+      load_tile(zt, z, nxt);
+      load_tile(dt, dy, nxt);
+    }
+    FENCE();
     h8 wh[NKK], wl[NKK];
     load_w(W13T, wh, wl);
     FENCE();
@@ -1230,6 +1236,8 @@ k_edge_update_bwd_fused(const f32x4* __restrict__ dy, const f32x4* __restrict__ 
       FENCE();
     }
     sacc_add(1, bacc12);
+    FENCE();
+    if (more) load_tile(t2, a2, nxt);  // (dead since the loop above)
     FENCE();
     load_w(W12T, wh, wl);
     FENCE();
@@ -1259,7 +1267,9 @@ k_edge_update_bwd_fused(const f32x4* __restrict__ dy, const f32x4* __restrict__ 
     load_w(W11bT, wh, wl);
     FENCE();
     FB_BARRIER();  // C
-    // ---- stage 3: dE = dz + W11b^T da1; dW11b += da1 (x) e
+    // ---- stage 3: dE = dz + W11b^T da1; dW11b += da1 (x) e.  The next residue's z / dy / a2 tiles are requested
+    //      BEFORE its GEMM (their registers are dead since stages 0 / 1): requested after it, the LayerNorm exchange at
+    //      the top of the loop waited out a full memory round trip per residue
     {
       f32x4* dst = const_cast<f32x4*>(tile_of(dE, node));
 #pragma unroll
@@ -1269,11 +1279,6 @@ k_edge_update_bwd_fused(const f32x4* __restrict__ dy, const f32x4* __restrict__ 
         __builtin_nontemporal_store(v, &dst[tile_off + (unsigned)c * 64u]);
         FENCE();
       }
-    }
-    if (more) {
-      load_tile(zt, z, nxt);
-      load_tile(dt, dy, nxt);
-      load_tile(t2, a2, nxt);
     }
     FENCE();
   }
