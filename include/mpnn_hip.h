@@ -440,6 +440,18 @@ int mpnn_node_update_bwd(const float* dY, const float* dPQ_blocks, const float* 
                          float* dvec640, float p_drop, uint32_t drop_seed, float* workspace, int workspace_floats,
                          void* stream);
 
+/* mpnn_node_update_bwd with the projections' gradients given one by one: dPQ_each is a HOST array of nproj device
+ * pointers, entry p = d PQ_p [n][128] wherever its producer left it, NULL = that projection received no gradient
+ * (autograd delivers them as separate tensors; stacking them for dPQ_blocks copies nproj x n x 128 floats per layer).
+ * Everything else as above. */
+int mpnn_node_update_bwd_each(const float* dY, const float* const* dPQ_each, const float* x1pre, const float* a_pre,
+                              const float* x2pre, const float* cnt, float cnt_const, const float* mask,
+                              const float* ln1_w, const float* ln1_b, const float* ln2_w, float scale,
+                              const float* WprojT_packed, int nproj, const float* WoutT_packed,
+                              const float* WinT_packed, const float* W3T_packed, int n_nodes, float* d_hV_in,
+                              float* d_gsum, float* x1, float* hid, float* d_a, float* d_o, float* d_dh, float* dvec640,
+                              float p_drop, uint32_t drop_seed, float* workspace, int workspace_floats, void* stream);
+
 /* mpnn_pack_linear_split for n 128x128 blocks in one launch per 16 blocks: block b is read at blocks[b] with row
  * stride ld[b] (out[o][i] = W[o * ld + i]), or transposed (out[o][i] = W[i * ld + o]) when transposed[b] != 0, and
  * written to packed + b * 16384 floats.  blocks / ld / transposed are HOST arrays of device pointers / ints. */

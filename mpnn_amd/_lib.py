@@ -82,6 +82,8 @@ SIGNATURES = {
     "mpnn_node_update_train": [_P, _P, _P, _F] + [_P] * 11 + [_F, _P, _P, _I, _I] + [_P] * 5 + [_F, ctypes.c_uint32, _P],
     "mpnn_node_update_bwd": [_P] * 6 + [_F] + [_P] * 4 + [_F, _P, _I, _P, _P, _P, _I] + [_P] * 8 +
                             [_F, ctypes.c_uint32, _P, _I, _P],
+    "mpnn_node_update_bwd_each": [_P] * 6 + [_F] + [_P] * 4 + [_F, _P, _I, _P, _P, _P, _I] + [_P] * 8 +
+                                 [_F, ctypes.c_uint32, _P, _I, _P],
     "mpnn_node_wgrad_batch": [_I] + [_P] * 9 + [_I, _P, _I, _P],
     "mpnn_pack_blocks": [_P, _P, _P, _I, _P, _P],
     "mpnn_feature_wgrad": [_P] * 7 + [_I] * 4 + [_P, _P, _P, _I, _P],

@@ -313,8 +313,12 @@ k_node_update_train(const float* __restrict__ hV_in, const float* __restrict__ g
 // order and stores vec_part[blockIdx.x][640]; the launcher's k_partials_reduce adds the workgroups in a fixed order
 // into dvec[0:640] (ln1.w, ln1.b, ln2.w, ln2.b, b3).  No floating-point atomics.
 // ---------------------------------------------------------------------------
+struct ProjGrads {  // d PQ_p [n][128] of each projection, wherever its producer left it (NULL: no gradient, zero)
+  const float* p[8];
+};
+
 __global__ void __launch_bounds__(256)
-k_node_update_bwd(const float* __restrict__ dY, const float* __restrict__ dPQ, const float* __restrict__ s_x1pre,
+k_node_update_bwd(const float* __restrict__ dY, ProjGrads dPQ, const float* __restrict__ s_x1pre,
                   const float* __restrict__ s_a, const float* __restrict__ s_x2pre, const float* __restrict__ cnt,
                   float cnt_const, const float* __restrict__ mask, const float* __restrict__ ln1w,
                   const float* __restrict__ ln1b, const float* __restrict__ ln2w, float inv_scale,
@@ -366,7 +370,8 @@ k_node_update_bwd(const float* __restrict__ dY, const float* __restrict__ dPQ, c
   for (int p = 0; p < nproj; ++p) {
 #pragma unroll
     for (int t = 0; t < MPNN_NT; ++t)
-      x[t][0] = *reinterpret_cast<const f32x4*>(dPQ + ((size_t)p * N + nd) * MPNN_H + 16 * t + 4 * g);
+      x[t][0] = dPQ.p[p] ? *reinterpret_cast<const f32x4*>(dPQ.p[p] + (size_t)nd * MPNN_H + 16 * t + 4 * g)
+                         : f32x4{0.f, 0.f, 0.f, 0.f};
     const float un = grad_to_bfrag<1>(x, bf, nullptr);
     zero_tile<1>(tmp);
     prefetch();
@@ -622,6 +627,33 @@ extern "C" int mpnn_node_update_train(const float* hV_in, const float* gsum, con
   MPNN_LAUNCH_CHECK();
 }
 
+static int node_update_bwd_launch(const float* dY, const ProjGrads& pg, const float* x1pre, const float* a_pre,
+                                  const float* x2pre, const float* cnt, float cnt_const, const float* mask,
+                                  const float* ln1_w, const float* ln1_b, const float* ln2_w, float scale,
+                                  const float* WprojT_packed, int nproj, const float* WoutT_packed,
+                                  const float* WinT_packed, const float* W3T_packed, int n_nodes, float* d_hV_in,
+                                  float* d_gsum, float* x1, float* hid, float* d_a, float* d_o, float* d_dh,
+                                  float* dvec640, float p_drop, uint32_t drop_seed, float* workspace,
+                                  int workspace_floats, void* stream) {
+  MPNN_CHECK_ARG(x1pre && a_pre && x2pre && mask && ln1_w && ln1_b && ln2_w && WoutT_packed && WinT_packed &&
+                     W3T_packed && d_hV_in && d_gsum && x1 && hid && d_a && d_o && d_dh && dvec640 && workspace &&
+                     n_nodes > 0,
+                 "mpnn_node_update_bwd: bad arguments");
+  const int n_wg = (n_nodes + 63) / 64;
+  MPNN_CHECK_ARG((long long)workspace_floats >= (long long)n_wg * 5 * MPNN_H,
+                 "mpnn_node_update_bwd: workspace too small (640 floats per 64 nodes)");
+  MPNN_CHECK_ARG(nproj >= 0 && nproj <= 8 && (nproj == 0 || WprojT_packed),
+                 "mpnn_node_update_bwd: 0 .. 8 projections, with their transposed weights");
+  MPNN_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mpnn_node_update_bwd: dropout probability must be in [0, 1)");
+  hipLaunchKernelGGL(k_node_update_bwd, dim3((n_nodes + 63) / 64), dim3(256), 0, (hipStream_t)stream, dY, pg,
+                     x1pre, a_pre, x2pre, cnt, cnt_const, mask, ln1_w, ln1_b, ln2_w, 1.0f / scale,
+                     (const h8*)WprojT_packed, nproj, (const h8*)WoutT_packed, (const h8*)WinT_packed,
+                     (const h8*)W3T_packed, n_nodes, d_hV_in, d_gsum, x1, hid, d_a, d_o, d_dh, workspace,
+                     make_drop(p_drop, drop_seed));
+  launch_partials_reduce(workspace, n_wg, 5 * MPNN_H, 5 * MPNN_H, dvec640, 1, (hipStream_t)stream);
+  MPNN_LAUNCH_CHECK();
+}
+
 extern "C" int mpnn_node_update_bwd(const float* dY, const float* dPQ_blocks, const float* x1pre, const float* a_pre,
                                     const float* x2pre, const float* cnt, float cnt_const, const float* mask,
                                     const float* ln1_w, const float* ln1_b, const float* ln2_w, float scale,
@@ -630,22 +662,31 @@ extern "C" int mpnn_node_update_bwd(const float* dY, const float* dPQ_blocks, co
                                     float* d_gsum, float* x1, float* hid, float* d_a, float* d_o, float* d_dh,
                                     float* dvec640, float p_drop, uint32_t drop_seed, float* workspace,
                                     int workspace_floats, void* stream) {
-  MPNN_CHECK_ARG(x1pre && a_pre && x2pre && mask && ln1_w && ln1_b && ln2_w && WoutT_packed && WinT_packed &&
-                     W3T_packed && d_hV_in && d_gsum && x1 && hid && d_a && d_o && d_dh && dvec640 && workspace &&
-                     n_nodes > 0,
-                 "mpnn_node_update_bwd: bad arguments");
-  const int n_wg = (n_nodes + 63) / 64;
-  MPNN_CHECK_ARG((long long)workspace_floats >= (long long)n_wg * 5 * MPNN_H,
-                 "mpnn_node_update_bwd: workspace too small (640 floats per 64 nodes)");
-  MPNN_CHECK_ARG(nproj == 0 || (WprojT_packed && dPQ_blocks), "mpnn_node_update_bwd: projections need WprojT and dPQ");
-  MPNN_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mpnn_node_update_bwd: dropout probability must be in [0, 1)");
-  hipLaunchKernelGGL(k_node_update_bwd, dim3((n_nodes + 63) / 64), dim3(256), 0, (hipStream_t)stream, dY, dPQ_blocks,
-                     x1pre, a_pre, x2pre, cnt, cnt_const, mask, ln1_w, ln1_b, ln2_w, 1.0f / scale,
-                     (const h8*)WprojT_packed, nproj, (const h8*)WoutT_packed, (const h8*)WinT_packed,
-                     (const h8*)W3T_packed, n_nodes, d_hV_in, d_gsum, x1, hid, d_a, d_o, d_dh, workspace,
-                     make_drop(p_drop, drop_seed));
-  launch_partials_reduce(workspace, n_wg, 5 * MPNN_H, 5 * MPNN_H, dvec640, 1, (hipStream_t)stream);
-  MPNN_LAUNCH_CHECK();
+  MPNN_CHECK_ARG(nproj >= 0 && nproj <= 8 && (nproj == 0 || dPQ_blocks) && n_nodes > 0,
+                 "mpnn_node_update_bwd: 0 .. 8 projections, with dPQ");
+  ProjGrads pg = {};
+  for (int p = 0; p < nproj; ++p) pg.p[p] = dPQ_blocks + (size_t)p * n_nodes * MPNN_H;
+  return node_update_bwd_launch(dY, pg, x1pre, a_pre, x2pre, cnt, cnt_const, mask, ln1_w, ln1_b, ln2_w, scale,
+                                WprojT_packed, nproj, WoutT_packed, WinT_packed, W3T_packed, n_nodes, d_hV_in, d_gsum, x1,
+                                hid, d_a, d_o, d_dh, dvec640, p_drop, drop_seed, workspace, workspace_floats, stream);
+}
+
+// the same with the projections' gradients given one by one (a HOST array of nproj device pointers, NULL = no gradient):
+// autograd hands them over as separate tensors, and stacking them first is a copy of nproj x n x 128 floats per layer
+extern "C" int mpnn_node_update_bwd_each(const float* dY, const float* const* dPQ_each, const float* x1pre,
+                                         const float* a_pre, const float* x2pre, const float* cnt, float cnt_const,
+                                         const float* mask, const float* ln1_w, const float* ln1_b, const float* ln2_w,
+                                         float scale, const float* WprojT_packed, int nproj, const float* WoutT_packed,
+                                         const float* WinT_packed, const float* W3T_packed, int n_nodes, float* d_hV_in,
+                                         float* d_gsum, float* x1, float* hid, float* d_a, float* d_o, float* d_dh,
+                                         float* dvec640, float p_drop, uint32_t drop_seed, float* workspace,
+                                         int workspace_floats, void* stream) {
+  MPNN_CHECK_ARG(nproj >= 0 && nproj <= 8 && (nproj == 0 || dPQ_each), "mpnn_node_update_bwd_each: 0 .. 8 projections");
+  ProjGrads pg = {};
+  for (int p = 0; p < nproj; ++p) pg.p[p] = dPQ_each[p];
+  return node_update_bwd_launch(dY, pg, x1pre, a_pre, x2pre, cnt, cnt_const, mask, ln1_w, ln1_b, ln2_w, scale,
+                                WprojT_packed, nproj, WoutT_packed, WinT_packed, W3T_packed, n_nodes, d_hV_in, d_gsum, x1,
+                                hid, d_a, d_o, d_dh, dvec640, p_drop, drop_seed, workspace, workspace_floats, stream);
 }
 
 static int launch_node_wgrads(const WgradJobs& jb, int n_rows, float* workspace, int workspace_floats, hipStream_t st) {

@@ -649,9 +649,11 @@ class NodeUpdateFn(torch.autograd.Function):
         dev = gsum.device
         N = gsum.shape[0]
         dY = dY.contiguous() if dY is not None else None
-        dPQb = wprojT = None
-        if nproj:
-            dPQb = torch.stack([d if d is not None else torch.zeros(N, H, device=dev) for d in dPQ])
+        wprojT = None
+        # the projections' gradients stay where their producers left them (stacked: a copy of nproj x N x 128 floats)
+        dPQ = [d.contiguous() if d is not None else None for d in dPQ]
+        import ctypes
+        dPQ_tab = (ctypes.c_void_p * max(nproj, 1))(*[ptr(d) for d in dPQ]) if nproj else None
         base = _pack_flat([(W, True) for W in Wp] + [(Wout[:, H * q:H * (q + 1)], True) for q in range(4)] +
                           [(Win[H * q:H * (q + 1)], True) for q in range(4)] + [(W3, True)])
         o = nproj * 16384
@@ -662,18 +664,20 @@ class NodeUpdateFn(torch.autograd.Function):
         hid, d_a = torch.empty(N, 4 * H, device=dev), torch.empty(N, 4 * H, device=dev)
         dvec = _zeros(dev, 5 * H)
         ws = _workspace(dev, N)
-        call("mpnn_node_update_bwd", ptr(dY), ptr(dPQb), ptr(x1pre), ptr(a_pre), ptr(x2pre), ptr(cnt), 0.0, ptr(mask),
+        call("mpnn_node_update_bwd_each", ptr(dY), dPQ_tab, ptr(x1pre), ptr(a_pre), ptr(x2pre), ptr(cnt), 0.0, ptr(mask),
              ptr(ln1w.detach().contiguous()), ptr(ln1b.detach().contiguous()), ptr(ln2w.detach().contiguous()),
              float(scale), ptr(wprojT), nproj, ptr(woutT), ptr(winT), ptr(w3T), N, ptr(d_hV_in), ptr(d_gsum), ptr(x1),
              ptr(hid), ptr(d_a), ptr(d_o), ptr(d_dh), ptr(dvec), float(p_drop), int(seed), ptr(ws), ws.numel(),
              stream_ptr())
+        live = [p for p in range(nproj) if dPQ[p] is not None]
         res = _node_wgrad_batch([(d_dh, gsum, False), (d_a, x1, True), (d_o, hid, True)] +
-                                [(dPQb[p], hV_out, ctx.has_bias[p]) for p in range(nproj)])
+                                [(dPQ[p], hV_out, ctx.has_bias[p]) for p in live])
         (dW3, _), (dWin, dbin), (dWout, dbout) = res[:3]
         grads = [None, d_hV_in, d_gsum, None, None, dW3, dvec[4 * H:], dvec[:H], dvec[H:2 * H], dWin, dbin, dWout, dbout,
                  dvec[2 * H:3 * H], dvec[3 * H:4 * H]]
-        for dWp, dbp in res[3:]:
-            grads += [dWp, dbp]
+        by_proj = dict(zip(live, res[3:]))
+        for p in range(nproj):  # (a projection nobody differentiated through gets no gradient: autograd reads None as 0)
+            grads += list(by_proj.get(p, (None, None)))
         return tuple(grads)
 
 
