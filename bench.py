@@ -233,7 +233,7 @@ def train_leg(a, dev, rank, world, dist, barrier, _lib):
     opt = AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2)   # mpnn_adamw_step: 3 launches for the 118 tensors
     b = synthetic_batch(B, L, seed=2000 + rank, device=dev)
     batch = (b["X"], b["S"], b["mask"], b["chain_M"], b["residue_idx"], b["chain_encoding_all"])
-    steps, warm = max(3, min(a.steps, 10)), 2
+    steps, warm = max(3, min(a.steps, 20)), 2   # (the GPU starts idle: a ~1 ms pipeline fill is spread over these)
 
     ar_events = []
 
