@@ -746,7 +746,9 @@ k_message_level(const f32x4* __restrict__ hE, const float* __restrict__ Pbuf, in
 // re-zeroing per layer and level.
 // ---------------------------------------------------------------------------
 #ifndef MPNN_LEVEL_RING
-#define MPNN_LEVEL_RING 8
+#define MPNN_LEVEL_RING 6  // weight fragments in flight per wave in the level kernels' node phase: 64 x 512 samples take
+                           // 7.94 / 7.74 / 7.57 / 7.69 / 8.27 ms at 4 / 5 / 6 / 8 / 12 (12 waves per workgroup leave 168
+                           // registers a wave: a deeper ring spills)
 #endif
 // residues per workgroup: 4 x 3 column tiles = one message item per wave (items of one wave run one after the other,
 // each with its own chain of dependent loads, so more residues per workgroup only lengthen the launch)
