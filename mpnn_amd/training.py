@@ -114,6 +114,12 @@ class Graph:
     def frag_numel(self):
         return self.N * 8 * self.KT * 256
 
+    def full_count(self):
+        """[N] tensor holding K: the decoder's neighbour count (reference :143: every slot counts), one per step."""
+        if getattr(self, "_full_count", None) is None:
+            self._full_count = torch.full((self.N,), float(self.K), device=self.E_idx64.device, dtype=torch.float32)
+        return self._full_count
+
 
 def _pack_flat(blocks):
     """blocks: list of (view [128,128] with unit inner stride, transposed?) -> their packed forms (f16 hi/lo A
@@ -380,8 +386,9 @@ class MessageFn(torch.autograd.Function):
         ctx.g, ctx.dec, ctx.slot, ctx.w_valid = g, dec, slot, w_valid
         ctx.save_for_backward(hE, a1, a2, W1b, W2)
         if dec:
-            cnt = torch.full((g.N,), float(g.K), device=dev, dtype=torch.float32)
+            cnt = g.full_count()
         ctx.mark_non_differentiable(cnt)
+        ctx.set_materialize_grads(False)  # (no zero tensor for cnt's "gradient": a fill launch per layer)
         return gsum, cnt
 
     @staticmethod
@@ -390,7 +397,7 @@ class MessageFn(torch.autograd.Function):
         g, dec = ctx.g, ctx.dec
         hE, a1, a2, W1b, W2 = ctx.saved_tensors
         dev = hE.device
-        dgsum = dgsum.contiguous()
+        dgsum = dgsum.contiguous() if dgsum is not None else torch.zeros(g.N, H, device=dev, dtype=torch.float32)
         rows = torch.empty(g.N * g.Kp, H, device=dev, dtype=torch.float32)
         dP = torch.empty(g.N, H, device=dev, dtype=torch.float32)
         slot = ctx.slot
@@ -738,7 +745,7 @@ def forward_train(model, X, S, mask, chain_M, residue_idx, chain_encoding_all, f
                 [(W1s[id(d_)][3], None) for d_ in dec])
 
     if enc and not has_occ:   # h_V = 0: P is the bias row, Q is zero (their weight blocks get zero gradients either way)
-        proj = [enc[0].W1.bias.float().expand(N, H), torch.zeros(N, H, device=dev, dtype=torch.float32)]
+        proj = [enc[0].W1.bias.float().expand(N, H), hV]  # (hV is the zero tensor here; both are only read)
     else:
         first = msg_blocks(enc[0]) if enc else dec_first_blocks()
         proj = [linear(hV, W, b) for W, b in first]
@@ -837,12 +844,15 @@ class SmoothedLossFn(torch.autograd.Function):
              float(weight), 1.0 / 2000.0, ptr(loss), ptr(total), ptr(d_lp), ptr(ws), ws.numel(), stream_ptr())
         ctx.save_for_backward(d_lp)
         ctx.mark_non_differentiable(loss)
+        ctx.set_materialize_grads(False)
         return loss, total
 
     @staticmethod
     @custom_bwd(device_type="cuda")
     def backward(ctx, _g_loss, g_total):
         (d_lp,) = ctx.saved_tensors
+        if g_total is None:
+            return None, None, None, None
         return d_lp * g_total, None, None, None
 
 
