@@ -644,6 +644,7 @@ class NodeUpdateFn(torch.autograd.Function):
         ctx.has_bias = [projs[2 * p + 1] is not None for p in range(nproj)]
         ctx.save_for_backward(gsum, cnt, mask, W3, ln1w, ln1b, Win, Wout, ln2w, hV_out, x1pre, a_pre, x2pre,
                               *[projs[2 * p] for p in range(nproj)])
+        ctx.set_materialize_grads(False)  # an output nobody differentiated through arrives as None, not as a zero tensor
         return (hV_out,) + tuple(PQ[p] for p in range(nproj))
 
     @staticmethod

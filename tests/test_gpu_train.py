@@ -749,3 +749,48 @@ def test_feature_wgrad_recomputes_the_chunks(kw, L):
         if c == 0:
             assert torch.equal(dbc, db)
     assert dF.abs().max().item() > 0
+
+
+def test_node_update_backward_with_an_unused_projection():
+    """NodeUpdateFn when one of its projections (and, separately, h' itself) receives no gradient: the backward kernel gets
+    a NULL entry in its pointer table (mpnn_node_update_bwd_each) instead of a zero tensor.  Gradients equal those of the
+    same graph with an explicit zero contribution."""
+    import mpnn_amd
+    from mpnn_amd import training as T
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(4)
+    model = mpnn_amd.ProteinMPNN(k_neighbors=16, augment_eps=0.0, dropout=0.0).to(dev)
+    lyr = model.encoder_layers[0]
+    N = 80
+    hV = torch.randn(N, 128, device=dev)
+    gsum = torch.randn(N, 128, device=dev, requires_grad=True)
+    cnt = torch.full((N,), 16.0, device=dev)
+    mask = torch.ones(N, device=dev)
+    Wa = (torch.randn(128, 128, device=dev) * 0.05).requires_grad_(True)
+    Wb = (torch.randn(128, 128, device=dev) * 0.05).requires_grad_(True)
+    ba = torch.randn(128, device=dev, requires_grad=True)
+
+    def run(use_b, use_h):
+        for p in list(lyr.parameters()) + [Wa, Wb, ba, gsum]:
+            p.grad = None
+        T._ZEROS.reset(dev)
+        h, (pa, pb) = T._node_update(lyr, hV, gsum, cnt, mask, 0.0, [(Wa, ba), (Wb, None)])
+        loss = (pa * pa).sum()
+        if use_b:
+            loss = loss + (pb * 0.0).sum()   # a zero gradient, delivered as a tensor
+        if use_h:
+            loss = loss + (h * 0.0).sum()
+        loss.backward()
+        return {n: (p.grad.clone() if p.grad is not None else None)
+                for n, p in [("gsum", gsum), ("Wa", Wa), ("ba", ba), ("Wb", Wb), ("W3", lyr.W3.weight),
+                             ("Win", lyr.dense.W_in.weight), ("ln2", lyr.norm2.weight)]}
+
+    ref = run(True, True)         # every output receives a (zero) gradient tensor
+    for use_b, use_h in ((False, True), (False, False)):
+        got = run(use_b, use_h)
+        for n in ref:
+            if n == "Wb":
+                assert got[n] is None or float(got[n].abs().max()) == 0.0
+                continue
+            assert torch.equal(got[n], ref[n]), n
