@@ -716,9 +716,14 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
     w2l[kk] = W2T[((wave * NKK + kk) * 2 + 1) * 64 + lane];
   }
   const h8* W1w = W1bT + (size_t)wave * NKK * 2 * 64 + lane;
-  f32x4 accW2[MPNN_NT], accW1[MPNN_NT];
+  // weight-gradient accumulators: this wave's 32 x 64 block of each 128 x 128 matrix, as two 32 x 32 MFMA tiles
+  // (rows 32 (wave >> 1) .., columns 64 (wave & 1) + 32 b ..)
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  f32x16 accW2[2], accW1[2];
 #pragma unroll
-  for (int j = 0; j < MPNN_NT; ++j) accW2[j] = accW1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) accW2[b][v] = accW1[b][v] = 0.f;
   __shared__ float sacc[MPNN_H];  // db2: one writer lane per word, in residue order (first touched after a barrier)
   if (threadIdx.x < MPNN_H) sacc[threadIdx.x] = 0.f;
   float vmax = 0.f;
@@ -727,37 +732,31 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
   const int bf_kk = wave >> 1, bf_half = (wave & 1) * 4;  // halves [bf_half, bf_half + 4) of k-step bf_kk
   const int G = gridDim.x;
 
-  // the contraction of one stage: acc[j] += sum_e A[row block of this wave][e] B[tile j][e]  (scaled by the stage's sc)
-  auto contract = [&](int st, f32x4 (&acc)[MPNN_NT]) {
-    // operands of one pair of output tiles at a time, the next pair's reads issued ahead of this pair's MFMAs (the
-    // fences keep hipcc from hoisting every LDS read of the stage to the top: 100 registers)
-    h4 bh[2][2], bl[2][2];
-    auto rd = [&](int buf, int c, int j0) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        bh[buf][u] = *reinterpret_cast<const h4*>(&sB[st][0][16 * (j0 + u) + col][16 * c + 4 * g]);
-        bl[buf][u] = *reinterpret_cast<const h4*>(&sB[st][1][16 * (j0 + u) + col][16 * c + 4 * g]);
-      }
+  // the contraction of one stage: acc += sum_e A[rows of this wave's block][e] B[columns of its block][e] (scaled by the
+  // stage's sc), on v_mfma_f32_32x32x16_f16: 16 edges per instruction, so the 48 edges of a residue are three steps with
+  // nothing padded (the 16x16x16 form this replaces runs at half the matrix pipe's rate: 72 instead of 18 x 2 issue
+  // slots per stage and wave), and a 32 x 64 block reads 96 plane rows per step where a 16 x 128 block read 144.
+  // Lane (r32, q) holds row / column r32 and edges 8 q .. 8 q + 7 of the step in BOTH operands (any assignment of
+  // register elements to k that is the same on both sides is a valid one).
+  const int r32 = lane & 31, q32 = lane >> 5;
+  const int arow = 32 * (wave >> 1) + r32, brow = 64 * (wave & 1) + r32;
+  auto contract = [&](int st, f32x16 (&acc)[2]) {
+    auto rd8 = [&](const _Float16* p) {  // eight consecutive halves at an 8-byte aligned address
+      const h4 lo4 = *reinterpret_cast<const h4*>(p), hi4 = *reinterpret_cast<const h4*>(p + 4);
+      return h8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
     };
-    rd(0, 0, 0);
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
-      const h4 ah = *reinterpret_cast<const h4*>(&sA[st][0][16 * wave + col][16 * c + 4 * g]);
-      const h4 al = *reinterpret_cast<const h4*>(&sA[st][1][16 * wave + col][16 * c + 4 * g]);
+      const int e0 = 16 * c + 8 * q32;
+      const h8 ah = rd8(&sA[st][0][arow][e0]), al = rd8(&sA[st][1][arow][e0]);
 #pragma unroll
-      for (int jp = 0; jp < MPNN_NT / 2; ++jp) {
-        const int cur = (c * (MPNN_NT / 2) + jp) & 1;
-        if (jp + 1 < MPNN_NT / 2) rd(cur ^ 1, c, 2 * (jp + 1));
-        else if (c + 1 < KT) rd(cur ^ 1, c + 1, 0);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int j = 2 * jp + u;
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh[cur][u], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl[cur][u], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh[cur][u], acc[j], 0, 0, 0);
-        }
-        FENCE();
+      for (int b = 0; b < 2; ++b) {
+        const h8 bh = rd8(&sB[st][0][brow + 32 * b][e0]), bl = rd8(&sB[st][1][brow + 32 * b][e0]);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
       }
+      FENCE();
     }
   };
   // one column tile of this wave's gradient tile (already scaled) -> its halves of the next GEMM's B fragments and its
@@ -943,12 +942,14 @@ k_message_bwd_fused(const float* __restrict__ dgsum, const f32x4* __restrict__ a
   }
   // this workgroup's partial sums: [dW2 | db2] and [dW1b | -]
   float* P = part + (size_t)blockIdx.x * 2 * WG_PART;
+  // (a 32 x 32 MFMA tile: register v of lane (r32, q) is row 8 (v / 4) + 4 q + v % 4, column r32)
 #pragma unroll
-  for (int j = 0; j < MPNN_NT; ++j)
+  for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      P[(16 * wave + 4 * g + r) * MPNN_H + 16 * j + col] = accW2[j][r] * un1;
-      P[WG_PART + (16 * wave + 4 * g + r) * MPNN_H + 16 * j + col] = accW1[j][r] * un2;
+    for (int v = 0; v < 16; ++v) {
+      const int o = (32 * (wave >> 1) + 8 * (v >> 2) + 4 * q32 + (v & 3)) * MPNN_H + 64 * (wave & 1) + 32 * b + r32;
+      P[o] = accW2[b][v] * un1;
+      P[WG_PART + o] = accW1[b][v] * un2;
     }
   __syncthreads();
   if (threadIdx.x < MPNN_H) {
