@@ -204,6 +204,12 @@ __device__ __forceinline__ f32x4 abl_mfma4(abl_h4 a, abl_h4 b, f32x4 c) {
   return c;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, x, y, z) abl_mfma4(a, b, c)
+typedef float abl_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ abl_f32x16 abl_mfma32(h8 a, h8 b, abl_f32x16 c) {
+  asm volatile("" ::"v"(a), "v"(b));
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) abl_mfma32(a, b, c)
 #endif
 
 struct BFrag {

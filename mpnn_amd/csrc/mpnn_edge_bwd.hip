@@ -1058,34 +1058,41 @@ k_edge_update_bwd_fused(const f32x4* __restrict__ dy, const f32x4* __restrict__ 
   const int bf_kk = wave >> 1, bf_half = (wave & 1) * 4;
   const int G = gridDim.x;
 
+  // acc[j] += sum_e A[own 16 rows][e] B[tile j][e] on v_mfma_f32_16x16x32_f16: lane (col, g) holds edges 4 g .. 4 g + 3
+  // of TWO edge tiles in either operand; a last odd tile is paired with zeros.  (The 16x16x16 form takes the same 16
+  // cycles for half the edges, so the zero half costs nothing, and 48 edges are two instruction slots per product
+  // instead of three.  Mixing the two forms on one accumulator gave wrong sums on gfx950 - see DESIGN 0b.)  The message
+  // kernel's 32 x 32 tiles save more, but read plane rows another wave wrote: this kernel's A planes are
+  // single-buffered on the promise that a wave reads only its own.
   auto contract = [&](int st, f32x4 (&acc)[MPNN_NT]) {
-    h4 bh[2][2], bl[2][2];
-    auto rd = [&](int buf, int c, int j0) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        bh[buf][u] = *reinterpret_cast<const h4*>(&sB[st][0][16 * (j0 + u) + col][16 * c + 4 * g]);
-        bl[buf][u] = *reinterpret_cast<const h4*>(&sB[st][1][16 * (j0 + u) + col][16 * c + 4 * g]);
-      }
+    constexpr int NP = (KT + 1) / 2;  // pairs of edge tiles
+    auto ld4 = [&](const _Float16* p) { return *reinterpret_cast<const h4*>(p); };
+    auto rd8 = [&](const _Float16* r, int p) {  // edges 32 p + 4 g .. and 32 p + 16 + 4 g ..
+      const h4 x = ld4(r + 32 * p);
+      const h4 y = 2 * p + 1 < KT ? ld4(r + 32 * p + 16) : h4{};
+      return h8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
     };
-    rd(0, 0, 0);
+    h8 ah[NP], al[NP];
 #pragma unroll
-    for (int c = 0; c < KT; ++c) {
-      const h4 ah = *reinterpret_cast<const h4*>(&sA[0][16 * wave + col][16 * c + 4 * g]);
-      const h4 al = *reinterpret_cast<const h4*>(&sA[1][16 * wave + col][16 * c + 4 * g]);
+    for (int p = 0; p < NP; ++p) {
+      ah[p] = rd8(&sA[0][16 * wave + col][4 * g], p);
+      al[p] = rd8(&sA[1][16 * wave + col][4 * g], p);
+    }
+    // B operands one step (an output tile x a pair of edge tiles: three MFMAs) ahead of their use
+    h8 bh[2], bl[2];
+    auto rd = [&](int s) {
+      bh[s & 1] = rd8(&sB[st][0][16 * (s / NP) + col][4 * g], s % NP);
+      bl[s & 1] = rd8(&sB[st][1][16 * (s / NP) + col][4 * g], s % NP);
+    };
+    rd(0);
 #pragma unroll
-      for (int jp = 0; jp < MPNN_NT / 2; ++jp) {
-        const int cur = (c * (MPNN_NT / 2) + jp) & 1;
-        if (jp + 1 < MPNN_NT / 2) rd(cur ^ 1, c, 2 * (jp + 1));
-        else if (c + 1 < KT) rd(cur ^ 1, c + 1, 0);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int j = 2 * jp + u;
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh[cur][u], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl[cur][u], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh[cur][u], acc[j], 0, 0, 0);
-        }
-        FENCE();
-      }
+    for (int s = 0; s < MPNN_NT * NP; ++s) {
+      const int j = s / NP, p = s % NP;
+      if (s + 1 < MPNN_NT * NP) rd(s + 1);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[p], bh[s & 1], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p], bl[s & 1], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p], bh[s & 1], acc[j], 0, 0, 0);
+      FENCE();
     }
   };
   auto publish_grad = [&](int st, int c, const f32x4 x) {

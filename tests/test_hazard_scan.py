@@ -58,3 +58,15 @@ def test_dpp_source_written_too_recently():
     assert kinds(bad) == ["D"]
     ok = asm("\tv_add_f32_e32 v4, v1, v2\n\t;;#ASMSTART\n\ts_nop 1\n\tv_add_f32_dpp v4, v4, v4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t;;#ASMEND")
     assert kinds(ok) == []
+
+
+def test_accumulator_passed_between_two_mfma_forms():
+    wide = "\tv_mfma_f32_16x16x32_f16 v[94:97], v[154:157], v[252:255], v[94:97]\n"
+    narrow = "\tv_mfma_f32_16x16x16_f16 v[94:97], v[208:209], v[246:247], v[94:97]\n"
+    assert kinds(asm(wide + narrow)) == ["X"]       # what hipcc made of the mixed contraction (wrong sums on the GPU)
+    assert kinds(asm(narrow + wide)) == ["X"]
+    assert kinds(asm(wide + "\ts_nop 3\n" + narrow)) == ["X"]
+    assert kinds(asm(wide + "\ts_nop 7\n" + narrow)) == []
+    assert kinds(asm(wide + wide)) == []            # one form: the hardware forwards the accumulator
+    other = "\tv_mfma_f32_16x16x16_f16 v[90:93], v[208:209], v[246:247], v[90:93]\n"
+    assert kinds(asm(wide + other)) == []           # no dependence

@@ -13,6 +13,10 @@ asm VALU instruction that
   D  is a DPP instruction reading a register a VALU instruction wrote fewer than two wait states earlier
   S  is a v_fma_mixlo/hi_f16 whose fp32 operand is not (a copy of) the operand its f16 hi half was converted from
   A  writes a register an MFMA reads as an operand fewer than two wait states later
+  X  (any MFMA, the compiler's own included) takes as an operand the result of an MFMA of a DIFFERENT form issued fewer
+     than MFMA_STATES wait states earlier: gfx950 forwards an accumulator between two MFMAs of one form only, and hipcc
+     (ROCm 7.2) pads nothing between v_mfma_f32_16x16x32_f16 and a dependent v_mfma_f32_16x16x16_f16 in either order
+     (tools/ubench/mixed_mfma_repro.hip: half the outputs wrong, from plain builtins)
 
 Round 3's f16-product featurizer bug was a T (a v_cvt_pk_f16_f32 asm straight behind v_exp_f32); the conversion is now
 left to the compiler, and this scan keeps the remaining asm statements (GELU tail, column sums, the lo halves of the
@@ -75,6 +79,17 @@ def scan(asm_text):
                         findings.append(f"A {kernel}: line {pl} '{pt}' feeds the MFMA at line {ln} {dist} wait states later")
                     dist += states(pt)
                     if dist >= 2:
+                        break
+                dist = 0
+                for j in range(k - 1, -1, -1):
+                    pl, pt, pa = block[j]
+                    if pt.startswith("v_mfma"):
+                        if pt.split()[0] != t.split()[0] and regs(operands(pt)[0]) & srcs:
+                            findings.append(f"X {kernel}: line {ln} '{t}' takes the result of '{pt}' (line {pl}), another "
+                                            f"MFMA form, {dist} wait states behind it")
+                        break  # a third MFMA further up has left the pipe by the time this one issues
+                    dist += states(pt)
+                    if dist >= MFMA_STATES:
                         break
             if a and t.startswith(("v_fma_mixlo_f16", "v_fma_mixhi_f16")):
                 # S: the lo half must be computed from the operand its hi half was converted from
