@@ -70,3 +70,12 @@ def test_accumulator_passed_between_two_mfma_forms():
     assert kinds(asm(wide + wide)) == []            # one form: the hardware forwards the accumulator
     other = "\tv_mfma_f32_16x16x16_f16 v[90:93], v[208:209], v[246:247], v[90:93]\n"
     assert kinds(asm(wide + other)) == []           # no dependence
+
+
+def test_wider_window_behind_the_32x32_forms():
+    wide = "\tv_mfma_f32_32x32x16_f16 v[0:15], v[90:93], v[130:133], v[0:15]\n"
+    small = "\tv_mfma_f32_16x16x32_f16 v[0:3], v[90:93], v[130:133], v[0:3]\n"
+    reader = "\ts_nop 7\n\ts_nop 1\n\t;;#ASMSTART\n\tv_max_f32 v20, 0, v2\n\t;;#ASMEND"   # 10 wait states later
+    assert "M" in kinds(asm(wide + reader))         # 16 passes are still writing
+    assert kinds(asm(small + reader)) == []
+    assert kinds(asm(wide + "\ts_nop 7\n\ts_nop 7\n\ts_nop 3\n" + reader.split("\n", 2)[2])) == []

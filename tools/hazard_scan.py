@@ -7,7 +7,8 @@ asm VALU instruction that
 
   T  reads a register written by a transcendental (v_exp / v_rcp / v_rsq / v_sqrt / v_log / v_sin / v_cos) in the
      instruction directly before it             (gfx950: one wait state between a transcendental and its VALU reader)
-  M  reads or overwrites the destination of an MFMA issued fewer than MFMA_STATES wait states earlier
+  M  reads or overwrites the destination of an MFMA issued fewer than MFMA_STATES wait states earlier (MFMA_STATES_32
+     behind a 32x32 form)
                                                 (matrix-pipe write -> VALU read / write)
   W  overwrites the C operand of an MFMA issued fewer than SRC_STATES wait states earlier (A and B are read at issue)
   D  is a DPP instruction reading a register a VALU instruction wrote fewer than two wait states earlier
@@ -32,8 +33,13 @@ import tempfile
 # before a v_cvt_pkrtz that rewrites an accumulator) is 8 wait states from the MFMA to a VALU write or read of its
 # result and 4 to a VALU overwrite of its C operand.  One instruction of any kind = one wait state, as hipcc counts.
 MFMA_STATES = 8
+MFMA_STATES_32 = 20  # the 32x32 forms run twice to four times as many passes: the table's worst case (16 passes + 2), + 2
 SRC_STATES = 4
 MFMA_PIPE = 1
+
+
+def mfma_states(text):
+    return MFMA_STATES_32 if "_32x32x" in text.split()[0] else MFMA_STATES
 TRANS = ("v_exp_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_log_", "v_sin_", "v_cos_")
 
 
@@ -84,12 +90,12 @@ def scan(asm_text):
                 for j in range(k - 1, -1, -1):
                     pl, pt, pa = block[j]
                     if pt.startswith("v_mfma"):
-                        if pt.split()[0] != t.split()[0] and regs(operands(pt)[0]) & srcs:
+                        if pt.split()[0] != t.split()[0] and dist < mfma_states(pt) and regs(operands(pt)[0]) & srcs:
                             findings.append(f"X {kernel}: line {ln} '{t}' takes the result of '{pt}' (line {pl}), another "
                                             f"MFMA form, {dist} wait states behind it")
                         break  # a third MFMA further up has left the pipe by the time this one issues
                     dist += states(pt)
-                    if dist >= MFMA_STATES:
+                    if dist >= MFMA_STATES_32:
                         break
             if a and t.startswith(("v_fma_mixlo_f16", "v_fma_mixhi_f16")):
                 # S: the lo half must be computed from the operand its hi half was converted from
@@ -143,7 +149,7 @@ def scan(asm_text):
                 pl, pt, pa = block[j]
                 if pt.startswith("v_mfma"):
                     mops = operands(pt)
-                    if regs(mops[0]) & live:
+                    if regs(mops[0]) & live and dist < mfma_states(pt):
                         findings.append(f"M {kernel}: line {ln} '{t}' {dist} wait states behind '{pt}' (line {pl})")
                     elif dist < SRC_STATES and regs(ops[0]) & live & regs(mops[-1]):
                         findings.append(f"W {kernel}: line {ln} '{t}' overwrites the C operand of '{pt}' (line {pl}) "
@@ -157,7 +163,7 @@ def scan(asm_text):
                     for x in operands(pt):
                         live -= regs(x)
                 dist += states(pt) if not pt.startswith("v_mfma") or j == k - 1 else MFMA_PIPE
-                if dist >= MFMA_STATES:
+                if dist >= MFMA_STATES_32:
                     break
         block.clear()
 
